@@ -1,0 +1,746 @@
+// csc_hip.hip -- gfx950 (MI355X) kernels + C ABI for batched convolutional OMP / MMP-DF.
+//
+// Hot kernel: mmp_level_kernel.  One 256-thread workgroup owns ONE tree node (signal s, frontier
+// index j of level d).  It
+//   1. loads the node's fp64 residual into LDS (fp64 + an fp32 copy),
+//   2. computes the node's full (P x K) correlation matrix on the fp32 matrix cores: the signal
+//      operand is the Hankel matrix A[p][l] = r[p + l], read straight out of the LDS-resident
+//      residual (one ds_read_b32 per fragment, no materialisation); the atom bank streams
+//      L2 -> LDS in 32-row slabs; 4 waves x (4 x 9) v_mfma_f32_16x16x4_f32 accumulators keep the
+//      whole matrix in registers (reference: src/csc/dictionary.py:395-407, src/csc/mmp.py:69),
+//   3. selects the node's children with the reference's multiplicative sibling suppression
+//      (src/csc/mmp.py:210-231): fp32 arg-max by wavefront reductions, then every entry within a
+//      guaranteed fp32 error band of the maximum is re-scored in fp64 so the selection equals the
+//      float64 reference's,
+//   4. solves each child's least squares on its support with an fp64 Gram / Cholesky in LDS
+//      (replaces lsqr on the masked operator, src/csc/mmp.py:65-68) and writes the child's
+//      residual, MSE, coefficients and (pos, atom).
+// Levels are launched one after the other (level-synchronous frontier, closed form of
+// src/csc/mmp.py:303-313,388-424); csc_reduce_kernel then extracts the per-sparsity winners
+// (src/csc/mmp.py:577-606, 458-467).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#include "../../include/csc_hip.h"
+
+#define WG 256
+#define SLAB 32
+#define MT 4
+#define NT 9
+#define CAND_CAP 64
+#define SUPP_BITS 0x7fc00001u          // quiet-NaN payload marking a suppressed entry (value 0)
+#define KMAX CSC_MAX_SPARSITY
+#define DELTA_REL 6.103515625e-05f      // 2^-14: fp32 candidate band, in units of ||residual||
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static thread_local char g_err[256] = "";
+#define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
+
+struct TreeShape {
+    int F[KMAX + 1];      // F[d] nodes at level d (F[0] = 1)
+    int off[KMAX + 2];    // node-id offset of level d (off[1] = 0)
+    int pw[KMAX + 1];     // min(connections^d, 2^30)
+};
+
+struct LevelArgs {
+    const float* bank32t; const double* bank64; const uint32_t* sim_bits;
+    int K, L, Lp, N, P, W;
+    int depth;            // level d of the parents expanded by this launch
+    int Kmax, connections, NN;
+    const double* resid_in;   // d == 0: signals [S][N]; else [S][F[d]][N]
+    double* resid_out;        // [S][F[d+1]][N] or nullptr (children are final leaves)
+    int32_t* node_pos; int32_t* node_atom; double* node_mse; double* node_coef;
+    int32_t* stats;
+    TreeShape ts;
+};
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(v, o);
+        int oi = __shfl_xor(i, o);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ bool is_supp(float x) { return __float_as_uint(x) == SUPP_BITS; }
+
+// Full (256 x 144) x Lp correlation tile on v_mfma_f32_16x16x4_f32.
+//   bank   : global, [Lr][144] f32 column tile of the packed bank, Lr = ceil32(L) rows allocated,
+//            rows >= L are zero; Lp = ceil8(L) rows are multiplied
+//   r32row : LDS, &r32[row_block + 64*wave + (lane & 15) + (lane >> 4)]
+//   slab   : LDS, 2 x SLAB x 144 floats
+// acc[mi][ni][reg] = C[row = 64*wave + 16*mi + 4*(lane>>4) + reg][col = 16*ni + (lane&15)]
+//
+// Staging: each 32-row slab (18 KiB) is copied global -> LDS by 18 global_load_lds_dwordx4
+// wave-instructions (1 KiB each, no VGPRs), issued before the MFMAs of the previous slab and
+// retired by the vmcnt(0) the compiler places in front of the slab's closing barrier.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void stage_slab(const float* gsrc, float* ldst, int wave, int lane) {
+    constexpr int PIECES = SLAB * CSC_TILE_COLS * 4 / 1024;           // 18
+#pragma unroll
+    for (int i = 0; i < (PIECES + 3) / 4; ++i) {
+        const int piece = wave + 4 * i;                               // wave-uniform
+        if (piece < PIECES)
+            __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + piece * 256 + lane * 4),
+                                             (lptr_t)(ldst + piece * 256), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void corr_tile_gemm(const float* __restrict__ bank, int Lp,
+                                               const float* r32row, float* slab,
+                                               f32x4 (&acc)[MT][NT]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nslab = (Lp + SLAB - 1) / SLAB;
+    stage_slab(bank, slab, wave, lane);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        if (s + 1 < nslab)
+            stage_slab(bank + (size_t)(s + 1) * SLAB * CSC_TILE_COLS,
+                       slab + ((s + 1) & 1) * (SLAB * CSC_TILE_COLS), wave, lane);
+        const float* sb = slab + (s & 1) * (SLAB * CSC_TILE_COLS) + lq * CSC_TILE_COLS + lr;
+        const float* ra = r32row + s * SLAB;
+        const int nks = min(SLAB, Lp - s * SLAB) >> 2;                // even (Lp % 8 == 0)
+        // two k-steps per iteration with ping-pong fragments: the LDS reads of the next k-step are
+        // issued in front of the 36 MFMAs of the current one
+        float a0[MT], b0[NT], a1[MT], b1[NT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) a0[mi] = ra[16 * mi];
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) b0[ni] = sb[16 * ni];
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ks += 2) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) a1[mi] = ra[16 * mi + 4 * (ks + 1)];
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) b1[ni] = sb[4 * (ks + 1) * CSC_TILE_COLS + 16 * ni];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
+            // the 7 LDS reads of the next k-step go out between the first MFMAs
+#pragma unroll
+            for (int g = 0; g < 7; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 22, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int kn = min(ks + 2, nks - 1);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) a0[mi] = ra[16 * mi + 4 * kn];
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) b0[ni] = sb[4 * kn * CSC_TILE_COLS + 16 * ni];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 7; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 22, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bank packing: [K][L] f64 -> [ceil(K/144)][Lp][144] f32 (zero padded)
+// ------------------------------------------------------------------------------------------------
+__global__ void bank_pack_kernel(const double* __restrict__ bank64, int K, int L, int Lp,
+                                 float* __restrict__ out, size_t total) {   // Lp = allocated rows
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int col = (int)(i % CSC_TILE_COLS);
+    const size_t t = i / CSC_TILE_COLS;
+    const int l = (int)(t % Lp);
+    const int chunk = (int)(t / Lp);
+    const int k = chunk * CSC_TILE_COLS + col;
+    out[i] = (k < K && l < L) ? (float)bank64[(size_t)k * L + l] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// similarity table: one workgroup per (k_sel, k); fp64 cross-correlation at every shift
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void sim_table_kernel(const double* __restrict__ bank64, int K, int L,
+                                                       int P, int W, double thr,
+                                                       uint32_t* __restrict__ bits) {
+    extern __shared__ double sm[];
+    double* a_sel = sm;            // [L]
+    double* a_k = sm + L;          // [L]
+    __shared__ double wpart[WG / 64];
+    const int ksel = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
+    double ss = 0.0;
+    for (int i = tid; i < L; i += WG) {
+        const double v = bank64[(size_t)ksel * L + i];
+        a_sel[i] = v;
+        a_k[i] = bank64[(size_t)k * L + i];
+        ss += v * v;
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) wpart[tid >> 6] = ss;
+    __syncthreads();
+    const double nrm = sqrt(wpart[0] + wpart[1] + wpart[2] + wpart[3]);
+    uint32_t* row = bits + ((size_t)ksel * K + k) * W;
+    const int nshift = 2 * P - 1;
+    for (int base = 0; base < W * 32; base += WG) {
+        const int dpi = base + tid;              // dp + P - 1
+        bool sup = false;
+        if (dpi < nshift) {
+            const int dp = dpi - (P - 1);
+            // corr = sum_j a_k[j] * a_sel[j + dp]
+            const int j0 = max(0, -dp), j1 = min(L, L - dp);
+            double acc = 0.0;
+            for (int j = j0; j < j1; ++j) acc = fma(a_k[j], a_sel[j + dp], acc);
+            sup = (acc / nrm) > thr;
+        }
+        const unsigned long long m = __ballot(sup);
+        const int w0 = (base + (tid & ~63)) >> 5;
+        if ((tid & 63) == 0) {
+            if (w0 < W) row[w0] = (uint32_t)m;
+            if (w0 + 1 < W) row[w0 + 1] = (uint32_t)(m >> 32);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone batched correlation (API parity: computeCorrelations)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG, 2) void correlate_kernel(const float* __restrict__ bank32t, int K, int L,
+                                                          int Lp, const double* __restrict__ signals,
+                                                          int N, int P, float* __restrict__ out) {
+    extern __shared__ float lds[];
+    const int R32 = CSC_TILE_ROWS * ((P + CSC_TILE_ROWS - 1) / CSC_TILE_ROWS) + Lp + 4;
+    float* slab = lds;
+    float* r32 = lds + 2 * SLAB * CSC_TILE_COLS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const size_t b = blockIdx.x;
+    for (int i = tid; i < R32; i += WG) r32[i] = (i < N) ? (float)signals[b * N + i] : 0.f;
+    __syncthreads();
+    const int nchunk = (K + CSC_TILE_COLS - 1) / CSC_TILE_COLS;
+    const int nrb = (P + CSC_TILE_ROWS - 1) / CSC_TILE_ROWS;
+    for (int rb = 0; rb < nrb; ++rb)
+        for (int ch = 0; ch < nchunk; ++ch) {
+            f32x4 acc[MT][NT];
+            corr_tile_gemm(bank32t + (size_t)ch * ((L + 31) & ~31) * CSC_TILE_COLS, Lp,
+                           r32 + rb * CSC_TILE_ROWS + 64 * wave + lr + lq, slab, acc);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int p = rb * CSC_TILE_ROWS + 64 * wave + 16 * mi + 4 * lq + rg;
+                        const int k = ch * CSC_TILE_COLS + 16 * ni + lr;
+                        if (p < P && k < K) out[(b * P + p) * K + k] = acc[mi][ni][rg];
+                    }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the level kernel
+// ------------------------------------------------------------------------------------------------
+struct SmallLds {
+    double G[KMAX][KMAX + 1];
+    double b[KMAX], x[KMAX], coefpar[KMAX];
+    double cand_val[CAND_CAP];
+    double wsum[WG / 64];
+    int cand_idx[CAND_CAP];
+    int sup_pos[KMAX], sup_atom[KMAX];
+    float wmax[WG / 64];
+    int widx[WG / 64], wsupp[WG / 64];
+    int cand_cnt, chosen, i32;
+    float m32;
+};
+
+__global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
+    extern __shared__ double lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int N = a.N, K = a.K, L = a.L, Lp = a.Lp, P = a.P, d = a.depth;
+
+    // ---- LDS carve-up ---------------------------------------------------------------------------
+    const int Npad = (N + 3) & ~3;
+    const int R32 = CSC_TILE_ROWS + Lp + 4;
+    float* slab = reinterpret_cast<float*>(lds_raw);                  // [2][SLAB][144]
+    uint32_t* simrow = reinterpret_cast<uint32_t*>(slab);             // aliases the slabs
+    double* r64 = lds_raw + (2 * SLAB * CSC_TILE_COLS) / 2;           // [Npad]
+    float* r32 = reinterpret_cast<float*>(r64 + Npad);                // [R32]
+    SmallLds* sl = reinterpret_cast<SmallLds*>(r32 + ((R32 + 3) & ~3));
+
+    // ---- which node ------------------------------------------------------------------------------
+    const int Fd = a.ts.F[d], Fc = a.ts.F[d + 1];
+    const size_t s = blockIdx.x / Fd;
+    const int j = (int)(blockIdx.x - s * Fd);
+    const int stride = a.ts.pw[d];
+    int nch = 0;
+    for (int r = 0; r < a.connections; ++r) {
+        if ((long long)j + (long long)r * stride < Fc) ++nch; else break;
+    }
+    const int k_child = d + 1;                                        // support size of the children
+
+    // ---- residual -> LDS, norm ---------------------------------------------------------------------
+    const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)N);
+    double ss = 0.0;
+    for (int i = tid; i < Npad; i += WG) {
+        const double v = (i < N) ? rin[i] : 0.0;
+        r64[i] = v;
+        ss = fma(v, v, ss);
+    }
+    for (int i = tid; i < R32; i += WG) r32[i] = (i < N) ? (float)rin[i] : 0.f;
+    // ancestors (root -> parent) and the parent's coefficients, loaded in parallel
+    if (tid < d) {
+        const int e = tid + 1;                                        // level of this ancestor
+        const size_t id = s * a.NN + a.ts.off[e] + (j % a.ts.pw[e]);
+        sl->sup_pos[tid] = a.node_pos[id];
+        sl->sup_atom[tid] = a.node_atom[id];
+        sl->coefpar[tid] = a.node_coef ? a.node_coef[(s * a.NN + a.ts.off[d] + j) * (size_t)a.Kmax + tid] : 0.0;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) sl->wsum[wave] = ss;
+    __syncthreads();
+    const double rnorm2 = sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3];
+    const float delta = DELTA_REL * (float)sqrt(rnorm2);
+
+    // ---- correlations on the matrix cores ------------------------------------------------------------
+    f32x4 acc[MT][NT];
+    corr_tile_gemm(a.bank32t, Lp, r32 + 64 * wave + lr + lq, slab, acc);
+
+    const int prow = 64 * wave + 4 * lq;          // + 16*mi + reg
+    const int base_idx = prow * K + lr;           // + (16*mi + reg)*K + 16*ni
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                if (prow + 16 * mi + rg >= P || 16 * ni + lr >= K) acc[mi][ni][rg] = -INFINITY;
+
+    // ---- children, one selection round per sibling -------------------------------------------------
+    for (int t = 0; t < nch; ++t) {
+        // (a) fp32 maximum (lowest index on ties)
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+                    const float x = acc[mi][ni][rg];
+                    const float e = is_supp(x) ? 0.f : x;
+                    if (e > bv) { bv = e; bi = base_idx + (16 * mi + rg) * K + 16 * ni; }
+                }
+        wave_argmax(bv, bi);
+        if (lane == 0) { sl->wmax[wave] = bv; sl->widx[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float m = sl->wmax[0]; int mi_ = sl->widx[0];
+            for (int w = 1; w < WG / 64; ++w) {
+                const float v = sl->wmax[w]; const int i = sl->widx[w];
+                if (v > m || (v == m && i < mi_)) { m = v; mi_ = i; }
+            }
+            sl->m32 = m; sl->i32 = mi_; sl->cand_cnt = 0;
+        }
+        __syncthreads();
+        const float tau = sl->m32 - delta;
+        const bool zero_band = (0.f >= tau);
+        // (b) every unsuppressed entry inside the fp32 error band of the maximum is a candidate
+        int first_supp = 0x7fffffff;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+                    const float x = acc[mi][ni][rg];
+                    const int idx = base_idx + (16 * mi + rg) * K + 16 * ni;
+                    if (is_supp(x)) {
+                        if (zero_band) first_supp = min(first_supp, idx);
+                    } else if (x >= tau) {
+                        const int slot = atomicAdd(&sl->cand_cnt, 1);
+                        if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
+                    }
+                }
+        if (zero_band) {
+            first_supp = wave_min(first_supp);
+            if (lane == 0) sl->wsupp[wave] = first_supp;
+        }
+        __syncthreads();
+        const int ncand_raw = sl->cand_cnt;
+        const int ncand = min(ncand_raw, CAND_CAP);
+        // (c) fp64 re-score: one wave per candidate
+        for (int c = wave; c < ncand; c += WG / 64) {
+            const int idx = sl->cand_idx[c];
+            const int p = idx / K, k = idx - p * K;
+            const double* at = a.bank64 + (size_t)k * L;
+            double v = 0.0;
+            for (int i = lane; i < L; i += 64) v = fma(at[i], r64[p + i], v);
+            v = wave_sum(v);
+            if (lane == 0) sl->cand_val[c] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int chosen;
+            if (ncand_raw > CAND_CAP) {
+                chosen = sl->i32;
+                if (a.stats) atomicAdd(&a.stats[0], 1);
+            } else {
+                double bestv = sl->cand_val[0]; int besti = sl->cand_idx[0];
+                for (int c = 1; c < ncand; ++c) {
+                    const double v = sl->cand_val[c]; const int i = sl->cand_idx[c];
+                    if (v > bestv || (v == bestv && i < besti)) { bestv = v; besti = i; }
+                }
+                if (zero_band) {
+                    int z = 0x7fffffff;
+                    for (int w = 0; w < WG / 64; ++w) z = min(z, sl->wsupp[w]);
+                    if (z != 0x7fffffff && (0.0 > bestv || (0.0 == bestv && z < besti))) besti = z;
+                }
+                chosen = besti;
+            }
+            sl->chosen = chosen;
+            sl->sup_pos[d] = chosen / K;
+            sl->sup_atom[d] = chosen - (chosen / K) * K;
+        }
+        __syncthreads();
+        const int p_sel = sl->sup_pos[d], k_sel = sl->sup_atom[d];
+        const int jc = j + t * stride;                               // child's index in level d+1
+        const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
+
+        // ---- child least squares: Gram + rhs (fp64 dots, one per wave at a time) ------------------
+        const int npair = k_child * (k_child + 1) / 2;
+        for (int q = wave; q < k_child + npair; q += WG / 64) {
+            double v = 0.0;
+            if (q < k_child) {
+                const double* at = a.bank64 + (size_t)sl->sup_atom[q] * L;
+                const int p = sl->sup_pos[q];
+                for (int i = lane; i < L; i += 64) v = fma(at[i], r64[p + i], v);
+                v = wave_sum(v);
+                if (lane == 0) sl->b[q] = v;
+            } else {
+                int r = q - k_child, i1 = 0;
+                while (r > i1) { r -= i1 + 1; ++i1; }               // (i1, i2 = r), i2 <= i1
+                const int i2 = r;
+                const double* a1 = a.bank64 + (size_t)sl->sup_atom[i1] * L;
+                const double* a2 = a.bank64 + (size_t)sl->sup_atom[i2] * L;
+                const int dp = sl->sup_pos[i1] - sl->sup_pos[i2];    // a2 index = i + dp
+                const int lo = max(0, -dp), hi = min(L, L - dp);
+                for (int i = lo + lane; i < hi; i += 64) v = fma(a1[i], a2[i + dp], v);
+                v = wave_sum(v);
+                if (lane == 0) { sl->G[i1][i2] = v; sl->G[i2][i1] = v; }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // in-place Cholesky G = C C^T (lower triangle), then C y = b, C^T x = y.
+            // A column that is numerically dependent on the earlier ones (re-selected activation)
+            // is decoupled and gets coefficient 0.
+            const int n = k_child;
+            bool bad = false;
+            for (int c = 0; c < n; ++c) {
+                const double g0 = sl->G[c][c];
+                double dg = g0;
+                for (int m = 0; m < c; ++m) dg -= sl->G[c][m] * sl->G[c][m];
+                if (!(dg > 1e-13 * g0)) {
+                    bad = true;
+                    for (int m = 0; m < c; ++m) sl->G[c][m] = 0.0;
+                    for (int r = c + 1; r < n; ++r) sl->G[r][c] = 0.0;
+                    sl->G[c][c] = 1.0;
+                    sl->b[c] = 0.0;
+                    continue;
+                }
+                const double piv = sqrt(dg);
+                sl->G[c][c] = piv;
+                for (int r = c + 1; r < n; ++r) {
+                    double v = sl->G[r][c];
+                    for (int m = 0; m < c; ++m) v -= sl->G[r][m] * sl->G[c][m];
+                    sl->G[r][c] = v / piv;
+                }
+            }
+            for (int r = 0; r < n; ++r) {
+                double v = sl->b[r];
+                for (int m = 0; m < r; ++m) v -= sl->G[r][m] * sl->x[m];
+                sl->x[r] = v / sl->G[r][r];
+            }
+            for (int r = n - 1; r >= 0; --r) {
+                double v = sl->x[r];
+                for (int m = r + 1; m < n; ++m) v -= sl->G[m][r] * sl->x[m];
+                sl->x[r] = v / sl->G[r][r];
+            }
+            if (bad && a.stats) atomicAdd(&a.stats[1], 1);
+        }
+        __syncthreads();
+        // ---- child residual, MSE ------------------------------------------------------------------
+        double* rout = a.resid_out ? a.resid_out + (s * Fc + jc) * (size_t)N : nullptr;
+        double cs = 0.0;
+        for (int n = tid; n < N; n += WG) {
+            double v = r64[n];
+            for (int i = 0; i < k_child; ++i) {
+                const int o = n - sl->sup_pos[i];
+                if (o >= 0 && o < L) v = fma(-sl->x[i], a.bank64[(size_t)sl->sup_atom[i] * L + o], v);
+            }
+            if (rout) rout[n] = v;
+            cs = fma(v, v, cs);
+        }
+        cs = wave_sum(cs);
+        if (lane == 0) sl->wsum[wave] = cs;
+        __syncthreads();
+        if (tid == 0) {
+            a.node_pos[cid] = p_sel;
+            a.node_atom[cid] = k_sel;
+            a.node_mse[cid] = (sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3]) / (double)N;
+        }
+        if (a.node_coef && tid < a.Kmax)
+            a.node_coef[cid * a.Kmax + tid] =
+                tid < k_child ? sl->x[tid] + (tid < d ? sl->coefpar[tid] : 0.0) : 0.0;
+
+        // ---- suppress the chosen atom's similarity disk for the next sibling ----------------------
+        if (t + 1 < nch) {
+            const int W = a.W;
+            const uint32_t* g = a.sim_bits + (size_t)k_sel * K * W;
+            for (int i = tid; i < K * W; i += WG) simrow[i] = g[i];
+            __syncthreads();
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int p = prow + 16 * mi + rg, k = 16 * ni + lr;
+                        if (p < P && k < K) {
+                            const int dpi = p - p_sel + P - 1;
+                            if ((simrow[k * W + (dpi >> 5)] >> (dpi & 31)) & 1u)
+                                acc[mi][ni][rg] = __uint_as_float(SUPP_BITS);
+                        }
+                    }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-sparsity winners (src/csc/mmp.py:577-606 '<=' = last minimum; :464 np.argmin = first)
+// ------------------------------------------------------------------------------------------------
+__global__ void reduce_kernel(int S, int Kmax, int NN, TreeShape ts, const int32_t* __restrict__ node_pos,
+                              const int32_t* __restrict__ node_atom, const double* __restrict__ node_mse,
+                              double* __restrict__ rec_mse, int32_t* __restrict__ rec_leaf,
+                              int32_t* __restrict__ rec_sel) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)S * Kmax) return;
+    const size_t s = i / Kmax;
+    const int k = (int)(i % Kmax) + 1;
+    const double* mse = node_mse + s * NN + ts.off[k];
+    double m = INFINITY;
+    int last = 0, first = 0;
+    for (int j = 0; j < ts.F[k]; ++j) {
+        const double v = mse[j];
+        if (v <= m) { if (v < m) first = j; m = v; last = j; }
+    }
+    // NaN-only levels keep leaf 0 (np.argmin returns the first NaN; '<=' never fires)
+    rec_mse[i] = node_mse[s * NN + ts.off[k] + last];
+    rec_leaf[2 * i] = last;
+    rec_leaf[2 * i + 1] = first;
+    int32_t* sel = rec_sel + i * Kmax * 2;
+    for (int e = 1; e <= Kmax; ++e) {
+        if (e <= k) {
+            const size_t id = s * NN + ts.off[e] + (last % ts.pw[e]);
+            sel[2 * (e - 1)] = node_pos[id];
+            sel[2 * (e - 1) + 1] = node_atom[id];
+        } else {
+            sel[2 * (e - 1)] = -1;
+            sel[2 * (e - 1) + 1] = -1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int ceil4(int v) { return (v + 3) & ~3; }
+static int ceil8(int v) { return (v + 7) & ~7; }
+static int ceil32(int v) { return (v + 31) & ~31; }
+
+static int make_shape(int Kmax, int c, int B, TreeShape* ts) {
+    if (Kmax < 1 || Kmax > KMAX) FAIL(-2, "max_sparsity %d outside [1, %d]", Kmax, KMAX);
+    if (c < 1 || c > CSC_MAX_CONNECTIONS) FAIL(-3, "connections %d outside [1, %d]", c, CSC_MAX_CONNECTIONS);
+    if (B < 1) FAIL(-4, "branches must be > 0 (got %d)", B);   // src/csc/mmp.py:409
+    long long pw = 1;
+    int off = 0;
+    ts->F[0] = 1; ts->pw[0] = 1; ts->off[0] = 0;
+    for (int d = 1; d <= Kmax; ++d) {
+        pw = (pw * c > (1LL << 30)) ? (1LL << 30) : pw * c;
+        ts->pw[d] = (int)pw;
+        ts->F[d] = (int)(pw < (long long)B ? pw : (long long)B);
+        ts->off[d] = off;
+        off += ts->F[d];
+        if (off > (1 << 24)) FAIL(-5, "tree too large (%d nodes)", off);
+    }
+    ts->off[Kmax + 1] = off;
+    for (int d = Kmax + 1; d <= KMAX; ++d) { ts->F[d] = 0; ts->pw[d] = 1; }
+    return off;
+}
+
+static size_t level_lds_bytes(int N, int Lp) {
+    const int Npad = ceil4(N);
+    const int R32 = CSC_TILE_ROWS + Lp + 4;
+    return (size_t)Npad * 8 + sizeof(SmallLds) + (size_t)ceil4(R32) * 4 + 2 * SLAB * CSC_TILE_COLS * 4;
+}
+
+extern "C" {
+
+int csc_abi_version(void) { return 1; }
+const char* csc_last_error(void) { return g_err; }
+
+size_t csc_bank32_elems(int K, int L) {
+    if (K <= 0 || L <= 0) return 0;
+    return (size_t)((K + CSC_TILE_COLS - 1) / CSC_TILE_COLS) * ceil32(L) * CSC_TILE_COLS;
+}
+
+int csc_sim_words(int N, int L) {
+    const int P = N - L + 1;
+    if (P <= 0) return 0;
+    return 2 * ((2 * P - 1 + 63) / 64);
+}
+
+int csc_bank_pack(const double* d_bank64, int K, int L, float* d_bank32t, void* stream) {
+    if (!d_bank64 || !d_bank32t || K <= 0 || L <= 0) FAIL(-1, "csc_bank_pack: bad arguments");
+    const size_t total = csc_bank32_elems(K, L);
+    hipLaunchKernelGGL(bank_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, d_bank64, K, L, ceil32(L), d_bank32t, total);
+    return (int)hipGetLastError();
+}
+
+int csc_similarity_table(const double* d_bank64, int K, int L, int N, double threshold,
+                         uint32_t* d_sim_bits, void* stream) {
+    const int P = N - L + 1;
+    if (!d_bank64 || !d_sim_bits || K <= 0 || L <= 0) FAIL(-1, "csc_similarity_table: bad arguments");
+    if (P <= 0) FAIL(-6, "signal length %d shorter than atom length %d", N, L);
+    if (K > 65535) FAIL(-7, "K = %d too large for the similarity table launch", K);
+    const int W = csc_sim_words(N, L);
+    hipLaunchKernelGGL(sim_table_kernel, dim3(K, K), dim3(WG), (size_t)2 * L * sizeof(double),
+                       (hipStream_t)stream, d_bank64, K, L, P, W, threshold, d_sim_bits);
+    return (int)hipGetLastError();
+}
+
+int csc_correlate(const float* d_bank32t, int K, int L, const double* d_signals, int B, int N,
+                  float* d_corr, void* stream) {
+    const int P = N - L + 1;
+    if (!d_bank32t || !d_signals || !d_corr || K <= 0 || L <= 0 || B < 0) FAIL(-1, "csc_correlate: bad arguments");
+    if (P <= 0) FAIL(-6, "signal length %d shorter than atom length %d", N, L);
+    if (B == 0) return 0;
+    const int Lp = ceil8(L);
+    const int R32 = CSC_TILE_ROWS * ((P + CSC_TILE_ROWS - 1) / CSC_TILE_ROWS) + Lp + 4;
+    const size_t lds = (size_t)ceil4(R32) * 4 + 2 * SLAB * CSC_TILE_COLS * 4;
+    if (lds > 160 * 1024) FAIL(-8, "signal too long for the LDS-resident correlation (%zu B)", lds);
+    hipFuncSetAttribute((const void*)correlate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(correlate_kernel, dim3(B), dim3(WG), lds, (hipStream_t)stream, d_bank32t, K, L, Lp,
+                       d_signals, N, P, d_corr);
+    return (int)hipGetLastError();
+}
+
+int csc_tree_nodes(int max_sparsity, int connections, int branches, int* level_sizes) {
+    TreeShape ts;
+    const int nn = make_shape(max_sparsity, connections, branches, &ts);
+    if (nn < 0) return nn;
+    if (level_sizes) for (int d = 1; d <= max_sparsity; ++d) level_sizes[d - 1] = ts.F[d];
+    return nn;
+}
+
+size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections, int branches) {
+    TreeShape ts;
+    if (make_shape(max_sparsity, connections, branches, &ts) < 0 || S <= 0 || N <= 0) return 0;
+    int fmax = 1;
+    for (int d = 1; d < max_sparsity; ++d) fmax = ts.F[d] > fmax ? ts.F[d] : fmax;
+    return 2 * (size_t)S * fmax * N * sizeof(double);
+}
+
+int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
+                    int K, int L, const double* d_signals, int S, int N,
+                    int max_sparsity, int connections, int branches,
+                    void* d_workspace, size_t workspace_bytes,
+                    int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse,
+                    double* d_node_coef, double* d_rec_mse, int32_t* d_rec_leaf,
+                    int32_t* d_rec_sel, int32_t* d_stats, void* stream) {
+    TreeShape ts;
+    const int NN = make_shape(max_sparsity, connections, branches, &ts);
+    if (NN < 0) return NN;
+    const int P = N - L + 1;
+    if (!d_bank32t || !d_bank64 || !d_signals || !d_node_pos || !d_node_atom || !d_node_mse)
+        FAIL(-1, "csc_mmpdf_batch: null pointer");
+    if (connections > 1 && !d_sim_bits) FAIL(-1, "csc_mmpdf_batch: similarity table required when connections > 1");
+    if (K <= 0 || L <= 0 || S < 0) FAIL(-1, "csc_mmpdf_batch: bad sizes");
+    if (P <= 0) FAIL(-6, "signal length %d shorter than atom length %d", N, L);
+    if (K > CSC_TILE_COLS || P > CSC_TILE_ROWS)
+        FAIL(-9, "dictionary (K = %d, P = %d) exceeds the register-resident tile (%d x %d)", K, P,
+             CSC_TILE_COLS, CSC_TILE_ROWS);
+    if (max_sparsity > P * K) FAIL(-2, "max_sparsity exceeds the number of activations");
+    if (S == 0) return 0;
+    const size_t need = csc_mmpdf_workspace_bytes(S, N, max_sparsity, connections, branches);
+    if (max_sparsity > 1 && (workspace_bytes < need || !d_workspace))
+        FAIL(-10, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    const int Lp = ceil8(L);
+    const int W = csc_sim_words(N, L);
+    const size_t lds = level_lds_bytes(N, Lp);
+    if (lds > 80 * 1024) FAIL(-8, "signal too long for the LDS-resident node kernel (%zu B)", lds);
+    if ((size_t)K * W * 4 > 2 * SLAB * CSC_TILE_COLS * 4) FAIL(-8, "similarity row does not fit the slab buffer");
+    hipFuncSetAttribute((const void*)mmp_level_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+
+    double* ws[2] = {static_cast<double*>(d_workspace), static_cast<double*>(d_workspace) + need / 16};
+    hipStream_t st = (hipStream_t)stream;
+    for (int d = 0; d < max_sparsity; ++d) {
+        LevelArgs a;
+        a.bank32t = d_bank32t; a.bank64 = d_bank64; a.sim_bits = d_sim_bits;
+        a.K = K; a.L = L; a.Lp = Lp; a.N = N; a.P = P; a.W = W;
+        a.depth = d; a.Kmax = max_sparsity; a.connections = connections; a.NN = NN;
+        a.resid_in = (d == 0) ? d_signals : ws[d & 1];
+        a.resid_out = (d + 1 < max_sparsity) ? ws[(d + 1) & 1] : nullptr;
+        a.node_pos = d_node_pos; a.node_atom = d_node_atom; a.node_mse = d_node_mse; a.node_coef = d_node_coef;
+        a.stats = d_stats; a.ts = ts;
+        const size_t grid = (size_t)S * ts.F[d];
+        if (grid > 0x7fffffffULL) FAIL(-11, "batch too large for one launch (%zu workgroups)", grid);
+        hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) FAIL((int)e, "mmp_level_kernel launch failed at level %d: %s", d, hipGetErrorString(e));
+    }
+    if (d_rec_mse && d_rec_leaf && d_rec_sel) {
+        const size_t tot = (size_t)S * max_sparsity;
+        hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, S, max_sparsity,
+                           NN, ts, d_node_pos, d_node_atom, d_node_mse, d_rec_mse, d_rec_leaf, d_rec_sel);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) FAIL((int)e, "reduce_kernel launch failed: %s", hipGetErrorString(e));
+    }
+    return 0;
+}
+
+}  // extern "C"

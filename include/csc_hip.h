@@ -1,0 +1,101 @@
+/* csc_hip.h -- C ABI of libcsc_hip.so: batched convolutional OMP / MMP-DF on MI355X (gfx950).
+ *
+ * The reference (yanisgomes/csc) is pure Python and has no FFI; its boundary for this path is the
+ * Python class API.  Each entry point below states which reference call site(s) it replaces
+ * (paths relative to the reference root).  The Python mirror of that API (csc_amd/) binds these
+ * symbols through ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer named d_* is DEVICE memory owned by the caller (hipMalloc / torch tensor);
+ *     the library allocates nothing and keeps no state between calls;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued on it
+ *     and the calls return without synchronising;
+ *   - return value 0 = success, negative = argument error (see csc_last_error()), positive = a
+ *     hipError_t from a launch;
+ *   - activation index convention is the reference's: idx = pos * K + atom
+ *     (src/csc/dictionary.py:436, src/csc/mmp.py:74).
+ */
+#ifndef CSC_HIP_H
+#define CSC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSC_TILE_COLS 144      /* atoms per column tile of the correlation kernel (9 x 16)   */
+#define CSC_TILE_ROWS 256      /* positions per row tile (4 waves x 4 x 16)                   */
+#define CSC_MAX_SPARSITY 16    /* largest tree depth / support size                           */
+#define CSC_MAX_CONNECTIONS 8  /* largest number of siblings per node                         */
+
+int csc_abi_version(void);
+const char* csc_last_error(void);
+
+/* Sizes of the packed dictionary images for K atoms of length L and signals of length N. */
+size_t csc_bank32_elems(int K, int L);          /* floats   in d_bank32t                        */
+int    csc_sim_words(int N, int L);             /* uint32 per (k_sel, k) row of d_sim_bits      */
+
+/* Atom-bank materialisation in HBM.  Replaces the per-call rebuild of the atom matrix in
+ * src/csc/dictionary.py:390,404 (np.array([atom() for atom in self.atoms])).
+ *   d_bank64  [K][L] f64 (row = atom, as getLocalDictionary(), src/csc/dictionary.py:112-113)
+ *   d_bank32t [ceil(K/144)][Lp][144] f32, Lp = ceil4(L): time-major, zero padded column tiles. */
+int csc_bank_pack(const double* d_bank64, int K, int L, float* d_bank32t, void* stream);
+
+/* Atom-vs-dictionary similarity table.  Replaces, for every node, the
+ * computeCorrelations(atom_signal)/||atom_signal|| <= thr mask of src/csc/mmp.py:92-93,196-201:
+ * bit (dp + P-1) of row (k_sel, k) is SET where the mask is 0, i.e. where the correlation of atom
+ * k_sel with atom k shifted by dp = pos - pos_sel exceeds `threshold` (shift invariant because
+ * every placement is 'valid').  d_sim_bits [K][K][csc_sim_words(N, L)] uint32. */
+int csc_similarity_table(const double* d_bank64, int K, int L, int N, double threshold,
+                         uint32_t* d_sim_bits, void* stream);
+
+/* Batched valid cross-correlation on fp32 MFMA.  Replaces CSCDictionary.computeCorrelations
+ * (src/csc/dictionary.py:395-407) for B signals at once.
+ *   d_signals [B][N] f64 ; d_corr [B][P][K] f32, P = N - L + 1. */
+int csc_correlate(const float* d_bank32t, int K, int L, const double* d_signals, int B, int N,
+                  float* d_corr, void* stream);
+
+/* Tree shape of runMMPDF (src/csc/mmp.py:303-313, 388-424): level d (1..max_sparsity) holds
+ * F_d = min(branches, connections^d) nodes; node j of level d has parent j mod connections^(d-1)
+ * and sibling rank j div connections^(d-1).  Writes F_1..F_max into level_sizes[max_sparsity]
+ * (may be NULL) and returns the number of non-root nodes per signal, or a negative error. */
+int csc_tree_nodes(int max_sparsity, int connections, int branches, int* level_sizes);
+
+/* Bytes of scratch csc_mmpdf_batch needs for S signals. */
+size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections, int branches);
+
+/* Batched MMP-DF / OMP: all signals x frontier nodes per level, one launch per level.
+ * Replaces the joblib fan-out over MMPTree(...).runMMPDF(...) of
+ * src/csc/dictionary.py:1047-1071,1147 (sparVar), :1012-1045 (mmpdf, tree dict) and, with
+ * connections = branches = 1, the omp loops of :492-552, :574-649.
+ *
+ * Node id of (level d, index j) is off_d + j with off_1 = 0, off_{d+1} = off_d + F_d; NN = total.
+ *   d_signals   [S][N] f64
+ *   d_node_pos  [S][NN] int32   selected position of the node      (src/csc/mmp.py:74-76)
+ *   d_node_atom [S][NN] int32   selected atom index
+ *   d_node_mse  [S][NN] f64     mean(residual^2) of the node       (src/csc/mmp.py:108-109)
+ *   d_node_coef [S][NN][max_sparsity] f64 or NULL: LS coefficients of the node's support against
+ *               the ORIGINAL signal, in root->leaf order (lsqr(masked_conv_op, signal),
+ *               src/csc/dictionary.py:528)
+ *   d_rec_mse   [S][max_sparsity] f64     per sparsity k: min leaf MSE of the depth-k tree
+ *   d_rec_leaf  [S][max_sparsity][2] int32  leaf index j of the LAST minimum ('<=',
+ *               src/csc/mmp.py:586) and of the FIRST minimum (np.argmin, src/csc/mmp.py:464)
+ *   d_rec_sel   [S][max_sparsity][max_sparsity][2] int32  (pos, atom) root->leaf of the last-min
+ *               leaf, -1 padded                                      (src/csc/mmp.py:257-265)
+ *   d_stats     [4] int32 or NULL (must be zeroed by the caller): [0] selections that fell back
+ *               to the fp32 arg-max (candidate overflow), [1] non-positive Cholesky pivots
+ */
+int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
+                    int K, int L, const double* d_signals, int S, int N,
+                    int max_sparsity, int connections, int branches,
+                    void* d_workspace, size_t workspace_bytes,
+                    int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse,
+                    double* d_node_coef, double* d_rec_mse, int32_t* d_rec_leaf,
+                    int32_t* d_rec_sel, int32_t* d_stats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSC_HIP_H */
