@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- signals/s of batched MMP-DF sparVar (connections 3, branches 3, max sparsity 5,
+dissimilarity 0.8) on MI355X, the metric of BASELINE.json.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "Config 2"): the 3200-signal sparVar sweep --
+200 constrained synthetic signals per (snr, sparsity) in product([0,5,10,15],[2,3,4,5]), N = 738,
+canonical 143-atom dictionary (L = 492), generator seed = rank.  One step = one pass of the hot path
+(csc_mmpdf_batch: 5 level launches + the per-sparsity reduction) over that batch with the signals
+already resident in HBM; with N > 1 every rank holds its own 3200 signals (weak scaling) and the
+step ends with the ONE gather of the fixed-size sparVar records on rank 0 over RCCL.
+
+Reported next to `value`:
+  roofline      fp32 MFMA roofline of the dominant kernel (mmp_level_kernel), launch durations
+                measured live with HIP events on the launch stream (csc_timer in include/csc_hip.h).
+                Algorithmic flops per signal = n_sel * 2*P*K*L, n_sel = 1 + sum_{d<5} min(B, c^d) = 13
+                (dense semantics of the reference, zero padding of the atoms NOT discounted).
+  cpu_baseline  the oracle's reference-faithful mode (oaconvolve over all atoms + lsqr defaults + one
+                fresh tree per sparsity = the reference's cost structure; kind "port" because the
+                reference's files cannot travel to the GPU box) on a bounded sample, rank 0, N = 1 only.
+"""
+import argparse
+import itertools
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+CONNECTIONS, BRANCHES, MAX_SPARSITY, DISSIMILARITY = 3, 3, 5, 0.8
+SIGNAL_LENGTH, PER_CELL = 738, 200
+SNR_LEVELS, SPARSITY_LEVELS = [0, 5, 10, 15], [2, 3, 4, 5]
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+CPU_SAMPLE = [i * PER_CELL + 7 for i in (0, 3, 5, 6, 9, 10, 12, 15)]   # one signal in 8 of the 16 cells
+
+
+def canonical_dictionary():
+    import csc_amd
+    return csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.005), np.arange(0.010, 0.036, 0.002), [1])
+
+
+def make_signals(dic, seed, per_cell=PER_CELL):
+    """Config-2 batch with the product's own generator (reference src/csc/dictionary.py:271-365)."""
+    np.random.seed(seed)
+    out = []
+    for snr, sp in itertools.product(SNR_LEVELS, SPARSITY_LEVELS):
+        for _ in range(per_cell):
+            s, _ = dic.generateConstrainedTestSignal(SIGNAL_LENGTH, sp, snr, 10, 0.75)
+            out.append(s)
+    return np.array(out)
+
+
+def _cpu_job(sig):
+    from oracle import csc_oracle as O
+    d = _cpu_job.dic if hasattr(_cpu_job, "dic") else O.canonical_dictionary()
+    _cpu_job.dic = d
+    t0 = time.time()
+    O.mmpdf_sparvar(d, {"id": 0, "snr": 0, "signal": sig}, CONNECTIONS, DISSIMILARITY, BRANCHES, MAX_SPARSITY,
+                    mode="faithful")
+    return time.time() - t0
+
+
+def cpu_baseline(signals):
+    """Reference-faithful CPU path on len(CPU_SAMPLE) signals, one process per signal."""
+    import multiprocessing as mp
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(len(CPU_SAMPLE), avail, int(os.environ.get("OMP_NUM_THREADS", "16") or 16)))
+    sample = [signals[i] for i in CPU_SAMPLE]
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_warm, range(cores))                    # imports + dictionary build, untimed
+        t0 = time.time()
+        per = pool.map(_cpu_job, sample, chunksize=1)
+        wall = time.time() - t0
+    return {"value": len(sample) / wall, "unit": "signals/s", "cores": cores, "kind": "port",
+            "sample": f"{len(sample)} of the {len(signals)} signals (indices {CPU_SAMPLE}), oracle mode "
+                      f"'faithful' (oaconvolve + lsqr, one tree per sparsity = 50 nodes/signal), "
+                      f"{sum(per):.1f} CPU-s, {np.mean(per):.2f} s/signal/core"}
+
+
+def _cpu_warm(_):
+    os.environ["OMP_NUM_THREADS"] = "1"
+    from oracle import csc_oracle as O
+    _cpu_job.dic = O.canonical_dictionary()
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--per-cell", type=int, default=PER_CELL, help="signals per (snr, sparsity) cell per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+
+    dic = canonical_dictionary()
+    signals = make_signals(dic, seed=rank, per_cell=a.per_cell)
+    S, N = signals.shape
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(signals if a.per_cell == PER_CELL else make_signals(dic, 0))   # before any GPU init
+
+    import torch
+    import torch.distributed as dist
+    from csc_amd import _lib
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    bank = dic.device_bank()
+    K, L = bank.K, bank.L
+    P = N - L + 1
+    sizes, NN = _lib.tree_shape(MAX_SPARSITY, CONNECTIONS, BRANCHES)
+    n_sel = 1 + sum(sizes[:-1])
+    flops_per_signal = n_sel * 2.0 * P * K * L
+
+    # PCIe-inclusive pass (host signals in, host records out) -- reported, never `value`
+    t0 = time.time()
+    d_sig = torch.from_numpy(signals).to(dev)
+    out = bank.mmpdf_launch(d_sig, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY, want_coef=False)
+    host_rec = out["rec_buf"].cpu()
+    torch.cuda.synchronize(dev)
+    first_call_s = time.time() - t0
+    t0 = time.time()
+    d_sig2 = torch.from_numpy(signals).to(dev)
+    bank.mmpdf_launch(d_sig2, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY, want_coef=False, out=out)
+    host_rec = out["rec_buf"].cpu()
+    torch.cuda.synchronize(dev)
+    pcie_s = time.time() - t0
+    del d_sig2
+
+    gathered = [torch.empty_like(out["rec_buf"]) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        bank.mmpdf_launch(d_sig, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY, want_coef=False, out=out)
+        if world > 1:
+            dist.gather(out["rec_buf"], gathered, dst=0)
+
+    for _ in range(a.warmup):
+        step()
+    timer = _lib.LevelTimer(capacity=a.steps * MAX_SPARSITY)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    with timer:
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    spans = timer.read()
+    timer.close()
+    stats = out["stats"].cpu().numpy().tolist()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_step = elapsed / a.steps * 1e3
+        value = world * S * a.steps / elapsed
+        launch_ms = float(np.mean([ms for _, ms in spans]))
+        per_level = {str(d): float(np.mean([ms for lv, ms in spans if lv == d])) for d in range(MAX_SPARSITY)}
+        flops_per_launch = S * flops_per_signal / MAX_SPARSITY       # 5 level launches share n_sel nodes
+        achieved = flops_per_launch / (launch_ms * 1e-3) / 1e12
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tf):
+            with open(tf) as f:
+                traffic = json.load(f).get("bytes_per_launch")
+        line = {
+            "metric": "signals/sec for MMP-DF (3 branches, sparsity<=5)", "value": value, "unit": "signals/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "config 2: 3200-signal sparVar sweep (sparsity 2-5 x SNR 0-15 dB, 200 each, "
+                                   "constrained), MMP-DF connections 3 / branches 3 / max sparsity 5 / "
+                                   "dissimilarity 0.8, per GPU",
+                       "signals_per_gpu": S, "signal_length": N, "atoms": K, "atom_length": L,
+                       "nodes_per_signal": NN, "parallelism": f"signals sharded over {world} rank(s), "
+                                                              "one RCCL gather of the sparVar records per step"
+                                                              if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "mmp_level_kernel", "launch_ms_avg": launch_ms, "launch_ms_by_level": per_level,
+                         "flops_per_launch": flops_per_launch, "flops_per_signal": flops_per_signal,
+                         "launches_timed": len(spans)},
+            "cpu_baseline": cpu,
+            "pcie_inclusive": {"value": S / pcie_s, "unit": "signals/s",
+                               "note": "one call: host f64 signals -> HBM, solve, sparVar records -> host",
+                               "first_call_s": first_call_s},
+            "fp32_argmax_fallbacks": stats[0], "duplicate_columns": stats[1],
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

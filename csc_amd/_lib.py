@@ -39,6 +39,13 @@ def lib():
             "csc_mmpdf_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
             "csc_mmpdf_batch": (i32, [vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, sz,
                                       vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+            "csc_timer_create": (vp, [i32]),
+            "csc_timer_destroy": (None, [vp]),
+            "csc_timer_attach": (None, [vp]),
+            "csc_timer_reset": (None, [vp]),
+            "csc_timer_count": (i32, [vp]),
+            "csc_timer_read": (i32, [vp, C.POINTER(C.c_float), C.POINTER(i32), i32]),
+            "csc_project_batch": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -49,7 +56,8 @@ def lib():
 
 EXPORTS = ("csc_abi_version", "csc_last_error", "csc_bank32_elems", "csc_sim_words", "csc_bank_pack",
            "csc_similarity_table", "csc_correlate", "csc_tree_nodes", "csc_mmpdf_workspace_bytes",
-           "csc_mmpdf_batch")
+           "csc_mmpdf_batch", "csc_project_batch", "csc_timer_create", "csc_timer_destroy", "csc_timer_attach",
+           "csc_timer_reset", "csc_timer_count", "csc_timer_read")
 
 
 def check(rc, what):
@@ -65,3 +73,41 @@ def tree_shape(max_sparsity, connections, branches):
     if nn < 0:
         check(nn, "csc_tree_nodes")
     return list(arr[:max_sparsity]), nn
+
+
+class LevelTimer:
+    """HIP-event spans around every level launch of csc_mmpdf_batch (include/csc_hip.h, csc_timer)."""
+
+    def __init__(self, capacity):
+        self._h = lib().csc_timer_create(int(capacity))
+        if not self._h:
+            raise CscHipError("csc_timer_create failed")
+        self.capacity = int(capacity)
+
+    def __enter__(self):
+        lib().csc_timer_reset(self._h)
+        lib().csc_timer_attach(self._h)
+        return self
+
+    def __exit__(self, *exc):
+        lib().csc_timer_attach(None)
+
+    def read(self):
+        """[(level, milliseconds)] -- call after the stream has been synchronised."""
+        n = lib().csc_timer_count(self._h)
+        ms, tag = (C.c_float * max(1, n))(), (C.c_int * max(1, n))()
+        got = lib().csc_timer_read(self._h, ms, tag, n)
+        if got < 0 or got != n:
+            check(got if got else -1, "csc_timer_read")
+        return [(int(tag[i]), float(ms[i])) for i in range(n)]
+
+    def close(self):
+        if self._h:
+            lib().csc_timer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -280,9 +280,127 @@ struct SmallLds {
     int sup_pos[KMAX], sup_atom[KMAX];
     float wmax[WG / 64];
     int widx[WG / 64], wsupp[WG / 64];
-    int cand_cnt, chosen, i32;
+    int cand_cnt, chosen, i32, bad;
     float m32;
 };
+
+// Least squares of the LDS-resident target r64 on the placed atoms sup_pos/sup_atom[0..n): fp64 Gram
+// and right-hand side by wave-wide dot products (one per wave at a time), in-place Cholesky
+// G = C C^T on one lane, C y = b, C^T x = y -> sl->x.  Replaces lsqr on the masked operator
+// (src/csc/mmp.py:65-67, src/csc/dictionary.py:471,528).  A column that is numerically dependent on
+// the earlier ones (an activation listed twice) is decoupled and gets coefficient 0; sl->bad flags it.
+// Contains workgroup barriers: every thread of the workgroup must call it.
+__device__ __forceinline__ void support_ls(SmallLds* sl, int n, const double* r64,
+                                           const double* __restrict__ bank64, int L) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int npair = n * (n + 1) / 2;
+    for (int q = wave; q < n + npair; q += WG / 64) {
+        double v = 0.0;
+        if (q < n) {
+            const double* at = bank64 + (size_t)sl->sup_atom[q] * L;
+            const int p = sl->sup_pos[q];
+            for (int i = lane; i < L; i += 64) v = fma(at[i], r64[p + i], v);
+            v = wave_sum(v);
+            if (lane == 0) sl->b[q] = v;
+        } else {
+            int r = q - n, i1 = 0;
+            while (r > i1) { r -= i1 + 1; ++i1; }               // (i1, i2 = r), i2 <= i1
+            const int i2 = r;
+            const double* a1 = bank64 + (size_t)sl->sup_atom[i1] * L;
+            const double* a2 = bank64 + (size_t)sl->sup_atom[i2] * L;
+            const int dp = sl->sup_pos[i1] - sl->sup_pos[i2];    // a2 index = i + dp
+            const int lo = max(0, -dp), hi = min(L, L - dp);
+            for (int i = lo + lane; i < hi; i += 64) v = fma(a1[i], a2[i + dp], v);
+            v = wave_sum(v);
+            if (lane == 0) { sl->G[i1][i2] = v; sl->G[i2][i1] = v; }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        bool bad = false;
+        for (int c = 0; c < n; ++c) {
+            const double g0 = sl->G[c][c];
+            double dg = g0;
+            for (int m = 0; m < c; ++m) dg -= sl->G[c][m] * sl->G[c][m];
+            if (!(dg > 1e-13 * g0)) {
+                bad = true;
+                for (int m = 0; m < c; ++m) sl->G[c][m] = 0.0;
+                for (int r = c + 1; r < n; ++r) sl->G[r][c] = 0.0;
+                sl->G[c][c] = 1.0;
+                sl->b[c] = 0.0;
+                continue;
+            }
+            const double piv = sqrt(dg);
+            sl->G[c][c] = piv;
+            for (int r = c + 1; r < n; ++r) {
+                double v = sl->G[r][c];
+                for (int m = 0; m < c; ++m) v -= sl->G[r][m] * sl->G[c][m];
+                sl->G[r][c] = v / piv;
+            }
+        }
+        for (int r = 0; r < n; ++r) {
+            double v = sl->b[r];
+            for (int m = 0; m < r; ++m) v -= sl->G[r][m] * sl->x[m];
+            sl->x[r] = v / sl->G[r][r];
+        }
+        for (int r = n - 1; r >= 0; --r) {
+            double v = sl->x[r];
+            for (int m = r + 1; m < n; ++m) v -= sl->G[m][r] * sl->x[m];
+            sl->x[r] = v / sl->G[r][r];
+        }
+        sl->bad = bad ? 1 : 0;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched projection on given supports (API parity: getSignalProjectionFromAtoms)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void project_kernel(const double* __restrict__ bank64, int K, int L, int P,
+                                                     const double* __restrict__ signals, int N,
+                                                     const int32_t* __restrict__ sig_index,
+                                                     const int32_t* __restrict__ support, int kmax,
+                                                     double* __restrict__ coef, double* __restrict__ mse,
+                                                     double* __restrict__ approx, int32_t* stats) {
+    extern __shared__ double lds_raw[];
+    double* r64 = lds_raw;                                            // [N]
+    SmallLds* sl = reinterpret_cast<SmallLds*>(r64 + ((N + 1) & ~1));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t m = blockIdx.x;
+    const size_t s = sig_index ? (size_t)sig_index[m] : m;
+    for (int i = tid; i < N; i += WG) r64[i] = signals[s * N + i];
+    if (tid == 0) {
+        // leading run of valid (pos, atom) pairs; an out-of-range pair ends the support
+        int n = 0;
+        for (; n < kmax; ++n) {
+            const int p = support[(m * kmax + n) * 2], k = support[(m * kmax + n) * 2 + 1];
+            if (p < 0 || p >= P || k < 0 || k >= K) break;
+            sl->sup_pos[n] = p;
+            sl->sup_atom[n] = k;
+        }
+        sl->cand_cnt = n;
+    }
+    __syncthreads();
+    const int n = sl->cand_cnt;
+    support_ls(sl, n, r64, bank64, L);
+    if (tid == 0 && sl->bad && stats) atomicAdd(&stats[1], 1);
+    double cs = 0.0;
+    for (int i = tid; i < N; i += WG) {
+        double ap = 0.0;
+        for (int q = 0; q < n; ++q) {
+            const int o = i - sl->sup_pos[q];
+            if (o >= 0 && o < L) ap = fma(sl->x[q], bank64[(size_t)sl->sup_atom[q] * L + o], ap);
+        }
+        if (approx) approx[m * N + i] = ap;
+        const double v = r64[i] - ap;
+        cs = fma(v, v, cs);
+    }
+    cs = wave_sum(cs);
+    if (lane == 0) sl->wsum[wave] = cs;
+    __syncthreads();
+    if (tid == 0 && mse) mse[m] = (sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3]) / (double)N;
+    if (coef && tid < kmax) coef[m * kmax + tid] = tid < n ? sl->x[tid] : 0.0;
+}
 
 __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     extern __shared__ double lds_raw[];
@@ -438,69 +556,9 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
         const int jc = j + t * stride;                               // child's index in level d+1
         const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
 
-        // ---- child least squares: Gram + rhs (fp64 dots, one per wave at a time) ------------------
-        const int npair = k_child * (k_child + 1) / 2;
-        for (int q = wave; q < k_child + npair; q += WG / 64) {
-            double v = 0.0;
-            if (q < k_child) {
-                const double* at = a.bank64 + (size_t)sl->sup_atom[q] * L;
-                const int p = sl->sup_pos[q];
-                for (int i = lane; i < L; i += 64) v = fma(at[i], r64[p + i], v);
-                v = wave_sum(v);
-                if (lane == 0) sl->b[q] = v;
-            } else {
-                int r = q - k_child, i1 = 0;
-                while (r > i1) { r -= i1 + 1; ++i1; }               // (i1, i2 = r), i2 <= i1
-                const int i2 = r;
-                const double* a1 = a.bank64 + (size_t)sl->sup_atom[i1] * L;
-                const double* a2 = a.bank64 + (size_t)sl->sup_atom[i2] * L;
-                const int dp = sl->sup_pos[i1] - sl->sup_pos[i2];    // a2 index = i + dp
-                const int lo = max(0, -dp), hi = min(L, L - dp);
-                for (int i = lo + lane; i < hi; i += 64) v = fma(a1[i], a2[i + dp], v);
-                v = wave_sum(v);
-                if (lane == 0) { sl->G[i1][i2] = v; sl->G[i2][i1] = v; }
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            // in-place Cholesky G = C C^T (lower triangle), then C y = b, C^T x = y.
-            // A column that is numerically dependent on the earlier ones (re-selected activation)
-            // is decoupled and gets coefficient 0.
-            const int n = k_child;
-            bool bad = false;
-            for (int c = 0; c < n; ++c) {
-                const double g0 = sl->G[c][c];
-                double dg = g0;
-                for (int m = 0; m < c; ++m) dg -= sl->G[c][m] * sl->G[c][m];
-                if (!(dg > 1e-13 * g0)) {
-                    bad = true;
-                    for (int m = 0; m < c; ++m) sl->G[c][m] = 0.0;
-                    for (int r = c + 1; r < n; ++r) sl->G[r][c] = 0.0;
-                    sl->G[c][c] = 1.0;
-                    sl->b[c] = 0.0;
-                    continue;
-                }
-                const double piv = sqrt(dg);
-                sl->G[c][c] = piv;
-                for (int r = c + 1; r < n; ++r) {
-                    double v = sl->G[r][c];
-                    for (int m = 0; m < c; ++m) v -= sl->G[r][m] * sl->G[c][m];
-                    sl->G[r][c] = v / piv;
-                }
-            }
-            for (int r = 0; r < n; ++r) {
-                double v = sl->b[r];
-                for (int m = 0; m < r; ++m) v -= sl->G[r][m] * sl->x[m];
-                sl->x[r] = v / sl->G[r][r];
-            }
-            for (int r = n - 1; r >= 0; --r) {
-                double v = sl->x[r];
-                for (int m = r + 1; m < n; ++m) v -= sl->G[m][r] * sl->x[m];
-                sl->x[r] = v / sl->G[r][r];
-            }
-            if (bad && a.stats) atomicAdd(&a.stats[1], 1);
-        }
-        __syncthreads();
+        // ---- child least squares on its support (fp64 Gram / Cholesky in LDS) ----------------------
+        support_ls(sl, k_child, r64, a.bank64, L);
+        if (tid == 0 && sl->bad && a.stats) atomicAdd(&a.stats[1], 1);
         // ---- child residual, MSE ------------------------------------------------------------------
         double* rout = a.resid_out ? a.resid_out + (s * Fc + jc) * (size_t)N : nullptr;
         double cs = 0.0;
@@ -617,6 +675,28 @@ static size_t level_lds_bytes(int N, int Lp) {
     return (size_t)Npad * 8 + sizeof(SmallLds) + (size_t)ceil4(R32) * 4 + 2 * SLAB * CSC_TILE_COLS * 4;
 }
 
+// ------------------------------------------------------------------------------------------------
+// optional per-launch HIP-event timer (bench.py's live roofline measurement)
+// ------------------------------------------------------------------------------------------------
+struct csc_timer {
+    int capacity, count;
+    hipEvent_t* ev;      // [2 * capacity]
+    int* tag;            // [capacity]
+};
+static thread_local csc_timer* g_timer = nullptr;
+
+static inline int timer_begin(hipStream_t st, int tag) {
+    csc_timer* t = g_timer;
+    if (!t || t->count >= t->capacity) return -1;
+    const int i = t->count++;
+    t->tag[i] = tag;
+    hipEventRecord(t->ev[2 * i], st);
+    return i;
+}
+static inline void timer_end(hipStream_t st, int i) {
+    if (i >= 0) hipEventRecord(g_timer->ev[2 * i + 1], st);
+}
+
 extern "C" {
 
 int csc_abi_version(void) { return 1; }
@@ -729,7 +809,9 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
         a.stats = d_stats; a.ts = ts;
         const size_t grid = (size_t)S * ts.F[d];
         if (grid > 0x7fffffffULL) FAIL(-11, "batch too large for one launch (%zu workgroups)", grid);
+        const int span = timer_begin(st, d);
         hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
+        timer_end(st, span);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) FAIL((int)e, "mmp_level_kernel launch failed at level %d: %s", d, hipGetErrorString(e));
     }
@@ -741,6 +823,61 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
         if (e != hipSuccess) FAIL((int)e, "reduce_kernel launch failed: %s", hipGetErrorString(e));
     }
     return 0;
+}
+
+int csc_project_batch(const double* d_bank64, int K, int L, const double* d_signals, int S, int N,
+                      const int32_t* d_sig_index, const int32_t* d_support, int M, int kmax,
+                      double* d_coef, double* d_mse, double* d_approx, int32_t* d_stats, void* stream) {
+    const int P = N - L + 1;
+    if (!d_bank64 || !d_signals || !d_support || K <= 0 || L <= 0 || S <= 0 || M < 0)
+        FAIL(-1, "csc_project_batch: bad arguments");
+    if (P <= 0) FAIL(-6, "signal length %d shorter than atom length %d", N, L);
+    if (kmax < 1 || kmax > KMAX) FAIL(-2, "support size %d outside [1, %d]", kmax, KMAX);
+    if (M == 0) return 0;
+    const size_t lds = (size_t)((N + 1) & ~1) * 8 + sizeof(SmallLds);
+    if (lds > 64 * 1024) FAIL(-8, "signal too long for the LDS-resident projection (%zu B)", lds);
+    hipLaunchKernelGGL(project_kernel, dim3((unsigned)M), dim3(WG), lds, (hipStream_t)stream, d_bank64, K, L, P,
+                       d_signals, N, d_sig_index, d_support, kmax, d_coef, d_mse, d_approx, d_stats);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL((int)e, "project_kernel launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+csc_timer* csc_timer_create(int capacity) {
+    if (capacity <= 0) return nullptr;
+    csc_timer* t = new csc_timer;
+    t->capacity = capacity; t->count = 0;
+    t->ev = new hipEvent_t[2 * (size_t)capacity];
+    t->tag = new int[capacity];
+    for (int i = 0; i < 2 * capacity; ++i)
+        if (hipEventCreate(&t->ev[i]) != hipSuccess) {
+            for (int j = 0; j < i; ++j) hipEventDestroy(t->ev[j]);
+            delete[] t->ev; delete[] t->tag; delete t;
+            return nullptr;
+        }
+    return t;
+}
+
+void csc_timer_destroy(csc_timer* t) {
+    if (!t) return;
+    if (g_timer == t) g_timer = nullptr;
+    for (int i = 0; i < 2 * t->capacity; ++i) hipEventDestroy(t->ev[i]);
+    delete[] t->ev; delete[] t->tag; delete t;
+}
+
+void csc_timer_attach(csc_timer* t) { g_timer = t; }
+void csc_timer_reset(csc_timer* t) { if (t) t->count = 0; }
+int csc_timer_count(const csc_timer* t) { return t ? t->count : 0; }
+
+int csc_timer_read(csc_timer* t, float* ms, int* tag, int n) {
+    if (!t || !ms || n < 0) FAIL(-1, "csc_timer_read: bad arguments");
+    const int m = n < t->count ? n : t->count;
+    for (int i = 0; i < m; ++i) {
+        hipError_t e = hipEventElapsedTime(&ms[i], t->ev[2 * i], t->ev[2 * i + 1]);
+        if (e != hipSuccess) FAIL((int)e, "csc_timer_read: span %d not complete: %s", i, hipGetErrorString(e));
+        if (tag) tag[i] = t->tag[i];
+    }
+    return m;
 }
 
 }  // extern "C"

@@ -55,6 +55,46 @@ class BatchResult:
     rec_sel: np.ndarray     # [S, K, K, 2] int32 (pos, atom)
     stats: np.ndarray       # [4] int32
 
+    _FIELDS = ("node_pos", "node_atom", "node_mse", "node_coef", "rec_mse", "rec_leaf", "rec_sel")
+
+    def __len__(self):
+        return self.node_pos.shape[0]
+
+    @staticmethod
+    def field_specs(max_sparsity, connections, branches, want_coef):
+        """(name, dtype, per-signal shape) of the fixed-size record of one signal."""
+        sizes, NN = _lib.tree_shape(max_sparsity, connections, branches)
+        K = max_sparsity
+        specs = [("node_pos", np.int32, (NN,)), ("node_atom", np.int32, (NN,)), ("node_mse", np.float64, (NN,))]
+        if want_coef:
+            specs.append(("node_coef", np.float64, (NN, K)))
+        specs += [("rec_mse", np.float64, (K,)), ("rec_leaf", np.int32, (K, 2)), ("rec_sel", np.int32, (K, K, 2))]
+        return specs
+
+    def to_records(self) -> np.ndarray:
+        """[S, rec_bytes] uint8: the per-signal fixed-size records that travel in the result gather
+        (csc_amd.distributed.gather_records)."""
+        S = len(self)
+        cols = [np.ascontiguousarray(getattr(self, n)).reshape(S, -1).view(np.uint8)
+                for n, _, _ in self.field_specs(self.max_sparsity, self.connections, self.branches,
+                                                self.node_coef is not None)]
+        return np.concatenate(cols, axis=1) if S else np.zeros((0, sum(c.shape[1] for c in cols)), np.uint8)
+
+    @classmethod
+    def from_records(cls, raw, max_sparsity, connections, branches, want_coef, stats=None):
+        sizes, NN = _lib.tree_shape(max_sparsity, connections, branches)
+        offs = [int(x) for x in np.concatenate([[0], np.cumsum(sizes)[:-1]])]
+        S = raw.shape[0]
+        f, at = {"node_coef": None}, 0
+        for n, dt, shp in cls.field_specs(max_sparsity, connections, branches, want_coef):
+            nb = int(np.prod(shp)) * np.dtype(dt).itemsize
+            f[n] = np.ascontiguousarray(raw[:, at:at + nb]).view(dt).reshape((S,) + shp)
+            at += nb
+        assert at == raw.shape[1], (at, raw.shape)
+        return cls(max_sparsity, connections, branches, sizes, offs, f["node_pos"], f["node_atom"],
+                   f["node_mse"], f["node_coef"], f["rec_mse"], f["rec_leaf"], f["rec_sel"],
+                   np.zeros(4, np.int32) if stats is None else stats)
+
     def node_id(self, depth, j):
         return self.level_offsets[depth - 1] + j
 
@@ -126,6 +166,35 @@ class DeviceBank:
             sig = sig[None]
         return sig.contiguous()
 
+    # ---- batched projection on given supports (getSignalProjectionFromAtoms) -------------------------
+    def project_batch(self, signals, supports, sig_index=None, want_approx=False):
+        """signals [S, N]; supports [M, kmax, 2] int32 (pos, atom), -1 padded; sig_index [M] or None.
+        Returns host (coef [M, kmax], mse [M], approx [M, N] | None, n_duplicate_columns)."""
+        sig = self._to_device(signals)
+        S, N = sig.shape
+        sup = np.ascontiguousarray(supports, dtype=np.int32)
+        M, kmax = sup.shape[0], sup.shape[1]
+        if sig_index is None and M > S:
+            raise ValueError("more problems than signals and no sig_index")
+        if sig_index is not None:
+            sig_index = np.ascontiguousarray(sig_index, dtype=np.int32)
+            if sig_index.shape != (M,) or (M and (sig_index.min() < 0 or sig_index.max() >= S)):
+                raise ValueError("sig_index out of range")
+        with torch.cuda.device(self.device):
+            d_sup = torch.from_numpy(sup).to(self.device)
+            d_idx = torch.from_numpy(sig_index).to(self.device) if sig_index is not None else None
+            coef = torch.empty((M, kmax), dtype=torch.float64, device=self.device)
+            mse = torch.empty((M,), dtype=torch.float64, device=self.device)
+            approx = torch.empty((M, N), dtype=torch.float64, device=self.device) if want_approx else None
+            stats = torch.zeros(4, dtype=torch.int32, device=self.device)
+            _lib.check(self.lib.csc_project_batch(_ptr(self.bank64), self.K, self.L, _ptr(sig), S, N,
+                                                  _ptr(d_idx), _ptr(d_sup), M, kmax, _ptr(coef), _ptr(mse),
+                                                  _ptr(approx), _ptr(stats), _stream(self.device)),
+                       "csc_project_batch")
+            torch.cuda.synchronize(self.device)
+        return (coef.cpu().numpy(), mse.cpu().numpy(), approx.cpu().numpy() if want_approx else None,
+                int(stats[1].item()))
+
     # ---- batched MMP-DF ------------------------------------------------------------------------------
     def mmpdf_launch(self, sig: torch.Tensor, max_sparsity, connections, branches, dissimilarity,
                      want_coef=True, out=None):
@@ -137,15 +206,21 @@ class DeviceBank:
         with torch.cuda.device(dev):
             if out is None:
                 ws_bytes = self.lib.csc_mmpdf_workspace_bytes(S, N, max_sparsity, connections, branches)
+                K = max_sparsity
+                # the per-sparsity records live in ONE buffer (what the multi-GPU gather sends):
+                # [S][K] f64 mse | [S][K][2] i32 leaf | [S][K][K][2] i32 (pos, atom)
+                rec = torch.empty(S * K * (16 + 8 * K), dtype=torch.uint8, device=dev)
+                o1, o2 = S * K * 8, S * K * 16
                 out = {
                     "ws": torch.empty(max(ws_bytes, 8) // 8, dtype=torch.float64, device=dev),
                     "node_pos": torch.empty((S, NN), dtype=torch.int32, device=dev),
                     "node_atom": torch.empty((S, NN), dtype=torch.int32, device=dev),
                     "node_mse": torch.empty((S, NN), dtype=torch.float64, device=dev),
-                    "node_coef": torch.empty((S, NN, max_sparsity), dtype=torch.float64, device=dev) if want_coef else None,
-                    "rec_mse": torch.empty((S, max_sparsity), dtype=torch.float64, device=dev),
-                    "rec_leaf": torch.empty((S, max_sparsity, 2), dtype=torch.int32, device=dev),
-                    "rec_sel": torch.empty((S, max_sparsity, max_sparsity, 2), dtype=torch.int32, device=dev),
+                    "node_coef": torch.empty((S, NN, K), dtype=torch.float64, device=dev) if want_coef else None,
+                    "rec_buf": rec,
+                    "rec_mse": rec[:o1].view(torch.float64).view(S, K),
+                    "rec_leaf": rec[o1:o2].view(torch.int32).view(S, K, 2),
+                    "rec_sel": rec[o2:].view(torch.int32).view(S, K, K, 2),
                     "stats": torch.zeros(4, dtype=torch.int32, device=dev),
                 }
             rc = self.lib.csc_mmpdf_batch(
@@ -164,7 +239,8 @@ class DeviceBank:
         torch.cuda.synchronize(self.device)
         sizes, NN = _lib.tree_shape(max_sparsity, connections, branches)
         offs = [int(x) for x in np.concatenate([[0], np.cumsum(sizes)[:-1]])]
-        cpu = {k: (v.cpu().numpy() if v is not None else None) for k, v in out.items() if k != "ws"}
+        cpu = {k: (v.cpu().numpy() if v is not None else None) for k, v in out.items()
+               if k not in ("ws", "rec_buf")}
         return BatchResult(max_sparsity, connections, branches, sizes, offs, cpu["node_pos"],
                            cpu["node_atom"], cpu["node_mse"], cpu["node_coef"], cpu["rec_mse"],
                            cpu["rec_leaf"], cpu["rec_sel"], cpu["stats"])

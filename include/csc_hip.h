@@ -7,7 +7,8 @@
  *
  * Conventions
  *   - every pointer named d_* is DEVICE memory owned by the caller (hipMalloc / torch tensor);
- *     the library allocates nothing and keeps no state between calls;
+ *     the library allocates no device memory and keeps no state between calls (except an attached
+ *     csc_timer, see below);
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued on it
  *     and the calls return without synchronising;
  *   - return value 0 = success, negative = argument error (see csc_last_error()), positive = a
@@ -94,6 +95,39 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
                     int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse,
                     double* d_node_coef, double* d_rec_mse, int32_t* d_rec_leaf,
                     int32_t* d_rec_sel, int32_t* d_stats, void* stream);
+
+/* Batched least-squares projection on GIVEN supports (fp64 Gram / Cholesky, one workgroup per
+ * problem).  Replaces CSCDictionary.getSignalProjectionFromAtoms (src/csc/dictionary.py:449-473:
+ * lsqr(masked_conv_op, signal) then op @ activations) and its callers
+ * MMPTree.getSubTreeFromMMPTreeDict / mmpdfCandidateFromMMPTreeDict / ompCandidateFromMMPTreeDict
+ * (src/csc/mmp.py:641-733) for M problems at once.
+ *   d_signals   [S][N] f64
+ *   d_sig_index [M] int32 or NULL: signal row of problem m (NULL: m itself, then M <= S); values must
+ *               lie in [0, S)
+ *   d_support   [M][kmax][2] int32 (pos, atom); the leading run of in-range pairs is the support,
+ *               pad the rest with -1.  An activation listed twice gets coefficient 0 the second
+ *               time (the reference's mask holds it once) and counts in d_stats[1].
+ *   d_coef      [M][kmax] f64 or NULL   LS coefficients in support order (0 beyond the support)
+ *   d_mse       [M] f64 or NULL         mean((signal - approx)^2)
+ *   d_approx    [M][N] f64 or NULL      the projection                                           */
+int csc_project_batch(const double* d_bank64, int K, int L, const double* d_signals, int S, int N,
+                      const int32_t* d_sig_index, const int32_t* d_support, int M, int kmax,
+                      double* d_coef, double* d_mse, double* d_approx, int32_t* d_stats, void* stream);
+
+/* Optional per-launch HIP-event timer.  No counterpart in the reference (its time_decorator,
+ * src/csc/dictionary.py:25-45, logs host wall-clock per method); bench.py uses it to measure the
+ * level kernel's launch durations live, on the stream the kernel runs on.  While a timer is
+ * attached (per host thread), csc_mmpdf_batch records one span per level launch, tagged with the
+ * level, until `capacity` spans are held.  Recording never synchronises; csc_timer_read must be
+ * called after the stream has been synchronised and returns the number of spans written
+ * (elapsed milliseconds + tags), or a negative / hipError_t code. */
+typedef struct csc_timer csc_timer;
+csc_timer* csc_timer_create(int capacity);
+void csc_timer_destroy(csc_timer* t);
+void csc_timer_attach(csc_timer* t);            /* NULL detaches */
+void csc_timer_reset(csc_timer* t);
+int  csc_timer_count(const csc_timer* t);
+int  csc_timer_read(csc_timer* t, float* ms, int* tag, int n);
 
 #ifdef __cplusplus
 }

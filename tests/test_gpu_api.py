@@ -1,0 +1,263 @@
+"""GPU tests of the drop-in API through libcsc_hip.so: the same assertions as tests/test_host_api_cpu.py
+(golden fixtures generated from the reference) with the REAL device bank, plus full-size property
+tests at BASELINE.json's batch size and the C-ABI error paths."""
+import itertools
+import json
+import os
+
+import numpy as np
+import pytest
+
+import test_host_api_cpu as H
+from conftest import load_json
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dic():
+    import csc_amd
+    return csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.005), np.arange(0.010, 0.036, 0.002), [1])
+
+
+def test_native_library_is_loaded(dic):
+    dic.device_bank()
+    assert any("libcsc_hip.so" in line for line in open("/proc/self/maps"))
+
+
+def test_sparvar_from_dict(dic, golden_signals):
+    H.test_sparvar_from_dict(dic, golden_signals)
+
+
+def test_sparvar_all_golden(dic, golden_signals):
+    sv = load_json("sparvar.json")
+    sub = golden_signals["signals"][::4]
+    for key, (c, B, K, thr) in {"c3_B3_K5_thr0.8": (3, 3, 5, 0.8), "c3_B10_K4_thr0.8": (3, 10, 4, 0.8)}.items():
+        for i, ref in enumerate(sv[key]):
+            got = dic.mmpdfSparVarFromDict({"id": ref["id"], "snr": ref["snr"], "signal": sub[i].tolist()}, c, thr, B, K)
+            H.check_sparvar(got, ref)
+
+
+def test_omp_from_dict(dic):
+    H.test_omp_from_dict(dic)
+
+
+def test_omp_config1_all_200(dic):
+    """BASELINE.json configs[0]: 200 constrained signals, sparsity 3, SNR 10 dB -- every atom list (in
+    the reference's descending-coefficient order), MSE and amplitude."""
+    ref = load_json("omp200.json")
+    np.random.seed(ref["seed"])
+    sigs = [dic.generateConstrainedTestSignal(738, 3, 10, 10, 0.75) for _ in range(200)]
+    res, _ = dic._batch(np.array([s for s, _ in sigs]), 3, 1, 1, 1.0, want_coef=True)
+    assert res.stats[0] == 0 and res.stats[1] == 0
+    for i, r in enumerate(ref["omp"]):
+        got = dic._omp_result({"id": i, "atoms": sigs[i][1]}, res, i, 738)
+        assert got["atoms"] == r["atoms"], i
+        assert abs(got["mse"] - r["mse"]) <= 1e-9 * r["mse"]
+        sup = res.branch(i, 3, 0)
+        for (p, k), c in zip(sup, res.node_coef[i, res.node_id(3, 0), :3]):
+            assert abs(c - r["coef"][str(p * 143 + k)]) <= 1e-8 * abs(c)
+
+
+def test_misc_drivers(dic, golden_signals):
+    H.test_misc_drivers(dic, golden_signals)
+
+
+def test_mmptree_view(dic, golden_signals):
+    H.test_mmptree_view(dic, golden_signals)
+
+
+def test_pipelines_json(dic, golden_signals, tmp_path):
+    H.test_sparvar_pipeline_json(dic, golden_signals, tmp_path)
+    H.test_other_pipelines_json(dic, golden_signals, tmp_path)
+
+
+def test_compute_correlations_api(dic, golden_signals):
+    z = np.load(os.path.join(H.ROOT, "tests", "golden", "rootcorr.npz"))
+    sig = golden_signals["signals"][int(z["sig_idx"][0])]
+    c = dic.computeCorrelations(sig)
+    assert c.shape == (247, 143) and c.dtype == np.float64
+    assert np.abs(c - z["corr"][0]).max() <= 3e-6 * np.linalg.norm(sig)
+    # synthesis of a sparse activation vector = the placed atoms
+    act = np.zeros(247 * 143)
+    act[10 * 143 + 5], act[200 * 143 + 99] = 2.0, -1.0
+    syn = dic.computeConvolutions(act)
+    ref = 2.0 * dic.getAtom(5).getAtomInSignal(738, 10) - dic.getAtom(99).getAtomInSignal(738, 200)
+    assert np.array_equal(syn, ref)
+
+
+def test_project_batch_duplicates_and_padding(dic, golden_signals):
+    bank = dic.device_bank()
+    sig = golden_signals["signals"][:3]
+    sup = np.full((3, 4, 2), -1, np.int32)
+    sup[0, :2] = [(10, 5), (100, 70)]
+    sup[1, :3] = [(10, 5), (100, 70), (10, 5)]          # duplicate activation
+    sup[2, :1] = [(246, 142)]
+    coef, mse, approx, ndup = bank.project_batch(sig, sup, sig_index=np.array([0, 0, 2], np.int32), want_approx=True)
+    assert ndup == 1
+    assert np.allclose(coef[0, :2], coef[1, :2], rtol=1e-12) and coef[1, 2] == 0 and (coef[0, 2:] == 0).all()
+    assert abs(mse[0] - mse[1]) <= 1e-15
+    from oracle import csc_oracle as O
+    od = O.canonical_dictionary()
+    ap, c = od.project(sig[0], [(10, 5), (100, 70)], 738, "faithful")       # lsqr, as the reference
+    assert np.allclose(coef[0, :2], c, rtol=1e-8) and np.allclose(approx[0], ap, atol=1e-10)
+    ap, c = od.project(sig[2], [(246, 142)], 738, "direct")
+    assert np.allclose(approx[2], ap, atol=1e-13) and abs(mse[2] - np.mean((sig[2] - ap) ** 2)) <= 1e-15
+    with pytest.raises(ValueError):
+        bank.project_batch(sig, sup, sig_index=np.array([0, 0, 3], np.int32))
+    approx0, acts = dic.getSignalProjectionFromAtoms(sig[0], [])
+    assert not approx0.any() and not acts.any()
+
+
+def test_abi_error_paths(dic):
+    from csc_amd import _lib
+    bank = dic.device_bank()
+    sig = np.zeros((2, 738))
+    with pytest.raises(_lib.CscHipError, match="max_sparsity"):
+        bank.mmpdf_batch(sig, 17, 3, 3, 0.8)
+    with pytest.raises(_lib.CscHipError, match="branches"):
+        bank.mmpdf_batch(sig, 3, 3, 0, 0.8)
+    with pytest.raises((ValueError, _lib.CscHipError), match="shorter"):
+        bank.mmpdf_batch(np.zeros((2, 400)), 3, 3, 3, 0.8)
+    with pytest.raises(AssertionError):
+        dic.mmpdf(np.zeros(738), 3, 3, 0.8, 0)
+    # empty batch is a no-op
+    res = bank.mmpdf_batch(np.zeros((0, 738)), 3, 3, 3, 0.8)
+    assert res.node_pos.shape == (0, 9)
+
+
+def test_zero_signal_edge_case(dic):
+    """all-zero residual: the reference gets NaN correlations and arg-max 0; with zero
+    correlations the first index wins here as well."""
+    res = dic.device_bank().mmpdf_batch(np.zeros((1, 738)), 2, 2, 2, 0.8)
+    assert res.node_pos[0, 0] == 0 and res.node_atom[0, 0] == 0
+    assert res.node_mse[0, 0] == 0.0
+
+
+def test_level_timer(dic, golden_signals):
+    import torch
+    from csc_amd import _lib
+    bank = dic.device_bank()
+    d = torch.from_numpy(golden_signals["signals"]).cuda()
+    t = _lib.LevelTimer(32)
+    with t:
+        bank.mmpdf_launch(d, 5, 3, 3, 0.8)
+        bank.mmpdf_launch(d, 5, 3, 3, 0.8)
+        torch.cuda.synchronize()
+    spans = t.read()
+    assert [lv for lv, _ in spans] == [0, 1, 2, 3, 4] * 2 and all(ms > 0 for _, ms in spans)
+    bank.mmpdf_launch(d, 5, 3, 3, 0.8)          # detached: nothing recorded
+    torch.cuda.synchronize()
+    assert len(t.read()) == 10
+    t.close()
+
+
+# ---- BASELINE.json full sizes: size-independent properties --------------------------------------------
+@pytest.fixture(scope="module")
+def config2(dic):
+    np.random.seed(0)
+    sigs, truth = [], []
+    for snr, sp in itertools.product([0, 5, 10, 15], [2, 3, 4, 5]):
+        for _ in range(200):
+            s, infos = dic.generateConstrainedTestSignal(738, sp, snr, 10, 0.75)
+            sigs.append(s)
+            truth.append(infos)
+    sigs = np.array(sigs)
+    return sigs, truth, dic.device_bank().mmpdf_batch(sigs, 5, 3, 3, 0.8, want_coef=True)
+
+
+def test_config2_full_batch_properties(dic, config2):
+    sigs, truth, res = config2
+    S = len(sigs)
+    assert S == 3200 and res.stats[0] == 0 and res.stats[1] == 0
+    bank64 = dic.getLocalDictionary()
+    # (1) a child never has a larger MSE than its parent; the root's children improve on the signal
+    for d in range(2, 6):
+        for j in range(3):
+            assert (res.node_mse[:, res.node_id(d, j)] <= res.node_mse[:, res.node_id(d - 1, j)] * (1 + 1e-12)).all()
+    # (2) per-sparsity record = the minimum over that level, '<=' picks the last minimum
+    for k in range(1, 6):
+        lvl = res.node_mse[:, res.node_id(k, 0):res.node_id(k, 0) + 3]
+        assert np.array_equal(res.rec_mse[:, k - 1], lvl.min(axis=1))
+        last = 2 - np.argmin(lvl[:, ::-1], axis=1)
+        assert np.array_equal(res.rec_leaf[:, k - 1, 0], last)
+        assert np.array_equal(res.rec_leaf[:, k - 1, 1], np.argmin(lvl, axis=1))
+    # (3) node MSE and coefficients agree with an independent fp64 normal-equation solve (every 16th signal)
+    for s in range(0, S, 16):
+        for j in range(3):
+            sup = res.branch(s, 5, j)
+            cols = np.zeros((738, 5))
+            for q, (p, k) in enumerate(sup):
+                cols[p:p + 492, q] = bank64[k]
+            coef, *_ = np.linalg.lstsq(cols, sigs[s], rcond=None)
+            r = sigs[s] - cols @ coef
+            nid = res.node_id(5, j)
+            assert abs(res.node_mse[s, nid] - np.mean(r ** 2)) <= 1e-9 * np.mean(r ** 2)
+            assert np.allclose(res.node_coef[s, nid], coef, rtol=1e-7, atol=1e-10)
+            # residual orthogonal to the selected atoms (what lsqr converges to in the reference)
+            assert np.abs(cols.T @ r).max() <= 1e-10
+    # (4) siblings differ and respect the dissimilarity rule at the root level
+    assert (res.node_pos[:, 0] * 143 + res.node_atom[:, 0] != res.node_pos[:, 1] * 143 + res.node_atom[:, 1]).all()
+
+
+def test_config2_depth_truncation_and_determinism(dic, config2):
+    """the depth-k tree is the truncation of the depth-5 tree (what lets ONE tree serve every sparVar
+    level), bit for bit, and a re-run is bit-identical."""
+    sigs, _, res = config2
+    bank = dic.device_bank()
+    r3 = bank.mmpdf_batch(sigs, 3, 3, 3, 0.8)
+    n3 = r3.node_pos.shape[1]
+    assert np.array_equal(r3.node_pos, res.node_pos[:, :n3]) and np.array_equal(r3.node_atom, res.node_atom[:, :n3])
+    assert np.array_equal(r3.node_mse, res.node_mse[:, :n3])
+    assert np.array_equal(r3.rec_sel[:, :, :, :], res.rec_sel[:, :3, :3, :])
+    again = bank.mmpdf_batch(sigs, 5, 3, 3, 0.8, want_coef=True)
+    for name in ("node_pos", "node_atom", "node_mse", "node_coef", "rec_mse", "rec_leaf", "rec_sel"):
+        assert np.array_equal(getattr(again, name), getattr(res, name)), name
+    # OMP = MMP-DF with one connection: same selections as branch '1-1-1-1-1'
+    omp = bank.mmpdf_batch(sigs, 5, 1, 1, 1.0)
+    for d in range(1, 6):
+        assert np.array_equal(omp.node_pos[:, d - 1], res.node_pos[:, res.node_id(d, 0)])
+        assert np.array_equal(omp.node_atom[:, d - 1], res.node_atom[:, res.node_id(d, 0)])
+
+
+def test_config2_vs_oracle_sample(dic, config2, oracle_dict):
+    """32 of the 3200 signals against the CPU oracle, every node."""
+    from oracle import csc_oracle as O
+    sigs, _, res = config2
+    for s in range(11, 3200, 100):
+        t = O.OracleTree(oracle_dict, sigs[s], 5, 3, 0.8, "direct")
+        t.run(3)
+        for path, (pos, atom, mse) in t.all_nodes().items():
+            digits = [int(x) for x in path.split("-")]
+            nid = res.node_id(len(digits), sum((o - 1) * 3 ** i for i, o in enumerate(digits)))
+            assert (int(res.node_pos[s, nid]), int(res.node_atom[s, nid])) == (pos, atom), (s, path)
+            assert abs(res.node_mse[s, nid] - mse) <= 1e-9 * mse
+
+
+def test_recovery_of_true_atoms_at_high_snr(dic, config2):
+    """sanity on the task itself: at 15 dB most true atoms are recovered by the best sparsity-matched record"""
+    import csc_amd
+    sigs, truth, res = config2
+    hits = total = 0
+    for s in range(2400, 3200, 10):
+        k = len(truth[s])
+        got = [dic._info(p, a) for p, a in res.rec_sel[s, k - 1, :k]]
+        tp, _ = csc_amd.computeMaxTruePositives(dic, 738, truth[s], got, 5, 0.9)
+        hits, total = hits + tp, total + k
+    assert hits / total > 0.8
+
+
+def test_gather_records_nccl_world1(dic, golden_signals):
+    """the RCCL gather path with a single rank (the 1-GPU box cannot host two NCCL ranks)"""
+    import torch.distributed as dist
+    from csc_amd import distributed as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        local = np.arange(35, dtype=np.uint8).reshape(7, 5)
+        assert np.array_equal(D.gather_records(local, 7), local)
+        res, _ = dic._batch(golden_signals["signals"][:5], 3, 3, 3, 0.8, sharded=True)
+        ref, _ = dic._batch(golden_signals["signals"][:5], 3, 3, 3, 0.8)
+        assert np.array_equal(res.node_pos, ref.node_pos) and np.array_equal(res.rec_mse, ref.rec_mse)
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,265 @@
+"""CPU tests of the HOST side of the drop-in API (result dictionaries, JSON pipelines, MMPTree view,
+sharding + the single gather with gloo at world_size 2).  The device is replaced by
+tests/helpers.OracleBank (the CPU oracle behind the DeviceBank interface) -- the HIP path itself is
+covered by the -m gpu tests, which run the same assertions through libcsc_hip.so."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_json
+from helpers import OracleBank, strip_delay
+
+
+@pytest.fixture(scope="module")
+def dic(oracle_dict):
+    import csc_amd
+    d = csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.005), np.arange(0.010, 0.036, 0.002), [1])
+    bank = OracleBank(oracle_dict)
+    d.device_bank = lambda: bank
+    return d
+
+
+def _close(a, b, rtol=1e-9):
+    return abs(a - b) <= rtol * abs(b)
+
+
+def check_sparvar(got, ref):
+    assert (got["id"], got["snr"]) == (ref["id"], ref["snr"])
+    assert len(got["results"]) == len(ref["results"])
+    for g, r in zip(got["results"], ref["results"]):
+        assert list(g) == ["mse", "path", "atoms", "delay"]
+        assert _close(g["mse"], r["mse"])
+        if g["path"] == r["path"]:
+            assert g["atoms"] == r["atoms"]
+        else:   # equal-support leaves: identical MSE up to rounding decides the '<=' winner
+            key = lambda a: (a["x"], float(a["b"]), float(a["y"]))
+            assert sorted(map(key, g["atoms"])) == sorted(map(key, r["atoms"]))
+
+
+def test_sparvar_from_dict(dic, golden_signals):
+    sv = load_json("sparvar.json")
+    sub = golden_signals["signals"][::4]
+    for i in (0, 5, 11):
+        ref = sv["c3_B3_K5_thr0.8"][i]
+        got = dic.mmpdfSparVarFromDict({"id": ref["id"], "snr": ref["snr"], "signal": sub[i].tolist()}, 3, 0.8, 3, 5)
+        check_sparvar(got, ref)
+    ref = sv["c3_B10_K4_thr0.8"][3]
+    got = dic.mmpdfSparVarFromDict({"id": ref["id"], "snr": ref["snr"], "signal": sub[3].tolist()}, 3, 0.8, 10, 4)
+    check_sparvar(got, ref)
+    json.dumps(got, default=__import__("csc_amd").handle_non_serializable)
+
+
+def test_omp_from_dict(dic):
+    ref = load_json("omp200.json")
+    np.random.seed(ref["seed"])
+    sigs = [dic.generateConstrainedTestSignal(738, 3, 10, 10, 0.75) for _ in range(12)]
+    for i in (0, 7, 11):
+        got = dic.ompFromDict({"id": i, "signal": sigs[i][0].tolist(), "atoms": sigs[i][1]})
+        r = ref["omp"][i]
+        assert list(got) == ["id", "mse", "sparsity", "approx", "atoms"]
+        assert got["atoms"] == r["atoms"] and got["sparsity"] == r["sparsity"] and _close(got["mse"], r["mse"])
+        approx, infos = dic.omp(sigs[i][0], 3)
+        assert infos == r["atoms"] and _close(np.mean((sigs[i][0] - approx) ** 2), r["mse"])
+        # amplitudes (getSignalProjectionFromAtoms) vs the reference's lsqr activations
+        ap2, acts = dic.getSignalProjectionFromAtoms(sigs[i][0], r["atoms"])
+        assert acts.shape == (247 * 143,) and np.count_nonzero(acts) == 3
+        for idx, c in r["coef"].items():
+            assert _close(acts[int(idx)], c, 1e-8)
+        assert np.allclose(ap2, approx, rtol=0, atol=1e-12)
+
+
+def test_misc_drivers(dic, golden_signals):
+    import csc_amd
+    misc = load_json("misc.json")
+    sigs = golden_signals["signals"]
+    for r in misc["mmpdf"]:
+        approx, infos = dic.mmpdf(sigs[r["id"]], 4, 3, 0.8, 5)
+        assert infos == r["infos"] and abs(approx.sum() - r["approx_sum"]) < 1e-9
+        assert np.allclose(approx[:4], r["approx_head"], atol=1e-15)
+    for r in misc["cmmp"]:
+        approx, infos = csc_amd.conv_multipath_matching_pursuit(sigs[r["id"]], dic, 3, 4)
+        assert infos == r["infos"] and abs(approx.sum() - r["approx_sum"]) < 1e-9
+    for r in misc["omp_sparvar"]:
+        got = dic.ompSparVarFromDict({"id": r["id"], "snr": r["snr"], "signal": sigs[r["id"]].tolist()}, 4)
+        assert (got["id"], got["snr"]) == (r["id"], r["snr"])
+        for g, x in zip(got["results"], r["results"]):
+            assert list(g) == ["mse", "atoms", "delay"]
+            assert g["atoms"] == x["atoms"] and _close(g["mse"], x["mse"])
+    for r in misc["tree_dict"]:
+        sd = {"id": r["id"], "signal": sigs[r["id"]].tolist(), "atoms": [None] * r["sparsity"]}
+        got = dic.mmpdfTreeFromDict(sd, 3, 0.8, 4)
+        assert got["id"] == r["id"] and got["sparsity"] == r["sparsity"]
+        assert list(got["mmp-tree"]) == list(r["mmp-tree"])
+        for p, v in r["mmp-tree"].items():
+            assert got["mmp-tree"][p]["atoms"] == v["atoms"] and _close(got["mmp-tree"][p]["mse"], v["mse"])
+
+
+def test_mmptree_view(dic, golden_signals):
+    import csc_amd
+    ref = load_json("trees.json")["c3_K5_B10_thr0.8"][2]
+    sig = golden_signals["signals"][8]
+    t = csc_amd.MMPTree(dic, sig, 5, 3, 0.8)
+    with pytest.raises(AssertionError):
+        t.runMMPDF(0)
+    t.runMMPDF(10)
+    assert ["-".join(map(str, p)) for p in t.leaves_paths] == ref["paths"]
+    for path, leaf in zip(ref["paths"], t.leaves_nodes):
+        pos, atom, mse, _ = ref["nodes"][path]
+        assert (leaf.atom_pos, leaf.atom_idx) == (pos, atom) and _close(leaf.getMSE(), mse)
+        assert leaf.getFullBranchPath() == path and leaf.isLeaf() and not leaf.isRoot()
+        n = leaf
+        while not n.parent.isRoot():
+            n = n.parent
+            p2 = n.getFullBranchPath()
+            assert (n.atom_pos, n.atom_idx) == tuple(ref["nodes"][p2][:2])
+    rec = t.buildMMPDFResultDict()
+    assert rec["path"] == ref["record"]["path"] and rec["atoms"] == ref["record"]["atoms"]
+    assert _close(rec["mse"], ref["record"]["mse"])
+    assert len(t.root.children) == 3 and t.root.children[0].getChildrenIndex() == 1
+    assert t.MMPDFBranchFromPath([1, 2, 1, 1, 1]) is t.leaves_nodes[3]
+    with pytest.raises(IndexError):
+        t.MMPDFBranchFromPath([3, 3, 3, 3, 3])
+    # residual of a leaf is orthogonal to its atoms, and reproduces the MSE
+    leaf = t.leaves_nodes[0]
+    res = leaf.getResidual()
+    assert _close(np.mean(res ** 2), leaf.getMSE(), 1e-9)
+    td = t.buildMMPTreeDict()
+    # offline helpers on stored tree dicts
+    assert csc_amd.MMPTree.getTreeParamsFromMMPTreeDict(td) == (5, 3)
+    sub = csc_amd.MMPTree.getSubTreeFromMMPTreeDict(td, dic, sig, 2)
+    for p, v in sub.items():
+        assert _close(v["mse"], ref["nodes"][p][2], 1e-8)
+    atoms, mse = csc_amd.MMPTree.ompCandidateFromMMPTreeDict(td, dic, sig, 3)
+    assert _close(mse, ref["nodes"]["1-1-1"][2], 1e-8) and len(atoms) == 3
+    atoms, mse = csc_amd.MMPTree.mmpdfCandidateFromMMPTreeDict(td, dic, sig, 3)
+    assert _close(mse, min(v[2] for p, v in ref["nodes"].items() if len(p) == 5), 1e-8)
+    assert len(csc_amd.MMPTree.shrinkMMPTreeDict(dict(td), 4)) == 4
+
+
+def _write_db(path, golden_signals, idx):
+    sigs = [{"id": int(i), "snr": int(golden_signals["snr"][i]), "sparsity": int(golden_signals["sparsity"][i]),
+             "signal": golden_signals["signals"][i].tolist(), "atoms": golden_signals["atoms"][i]} for i in idx]
+    db = {"date": "241008", "batchSize": 1, "snrLevels": [0, 5, 10, 15], "signalLength": 738,
+          "sparsityLevels": [2, 3, 4, 5], "dictionary": "x", "signals": sigs}
+    with open(path, "w") as f:
+        json.dump(db, f)
+
+
+def test_sparvar_pipeline_json(dic, golden_signals, tmp_path):
+    idx = list(range(0, 64, 4))[:6]
+    src, dst = str(tmp_path / "db.json"), str(tmp_path / "out.json")
+    _write_db(src, golden_signals, idx)
+    dic.mmpdfSparVarPipelineFromDB(src, dst, nb_cores=4, connections=3, dissimilarity=0.8, branches=3, max_sparsity=5)
+    out = json.load(open(dst))
+    assert list(out) == ["source", "date", "algorithm", "nbBranches", "connections", "dissimilarity",
+                         "maxSparsityLevel", "batchSize", "snrLevels", "signalLength", "sparsityLevels",
+                         "dictionary", "mmp"]
+    assert out["algorithm"] == "Convolutional MMP-DF" and out["dictionary"] == "CSCMeasurementMatrix object with 143 different atoms"
+    assert open(dst).read().startswith('{\n    "source"')          # indent=4
+    ref = load_json("sparvar.json")["c3_B3_K5_thr0.8"]
+    for got, r in zip(out["mmp"], ref[:6]):
+        check_sparvar(got, r)
+    with pytest.raises(ValueError):
+        open(src, "w").write("null")
+        dic.mmpdfSparVarPipelineFromDB(src, dst, 1)
+
+
+def test_other_pipelines_json(dic, golden_signals, tmp_path):
+    idx = [5, 21, 37]
+    src = str(tmp_path / "db.json")
+    _write_db(src, golden_signals, idx)
+    misc = load_json("misc.json")
+    dic.mmpdfPipelineFromDB(src, str(tmp_path / "t.json"), 1, connections=3, dissimilarity=0.8, branches=4)
+    out = json.load(open(tmp_path / "t.json"))
+    assert list(out)[-1] == "mmp" and "maxSparsityLevel" not in out
+    for got, r in zip(out["mmp"], misc["tree_dict"]):
+        assert strip_delay(got)["mmp-tree"].keys() == r["mmp-tree"].keys() and got["id"] == r["id"]
+        for p, v in r["mmp-tree"].items():
+            assert got["mmp-tree"][p]["atoms"] == v["atoms"]
+    dic.ompSparVarPipelineFromDB(src, str(tmp_path / "o.json"), 1, 4)
+    out = json.load(open(tmp_path / "o.json"))
+    assert out["algorithm"] == "Convolutional OMP" and out["maxSparsityLevel"] == 4
+    for got, r in zip(out["omp"], misc["omp_sparvar"]):
+        for g, x in zip(got["results"], r["results"]):
+            assert g["atoms"] == x["atoms"] and _close(g["mse"], x["mse"])
+    dic.ompPipelineFromDB(src, str(tmp_path / "p.json"), 1)
+    out = json.load(open(tmp_path / "p.json"))
+    assert [o["sparsity"] for o in out["omp"]] == [int(golden_signals["sparsity"][i]) for i in idx]
+    assert len(out["omp"][0]["approx"]) == 738
+
+
+def test_workbench_shell(dic, golden_signals, tmp_path):
+    import csc_amd
+    src = str(tmp_path / "db.json")
+    _write_db(src, golden_signals, [0, 4])
+    wb = csc_amd.CSCWorkbench(src)
+    wb.set_dictionary(dic)
+    assert wb.signalDictFromId(4)["id"] == 4 and wb.signalDictFromId(99) is None
+    wb.runMMPDFSparVar(str(tmp_path / "o.json"), 3, 0.8, 3, 2)
+    assert len(json.load(open(tmp_path / "o.json"))["mmp"]) == 2
+
+
+def test_metrics_utils(dic, golden_signals):
+    import csc_amd
+    truth = golden_signals["atoms"][9]
+    tp, matched = csc_amd.computeMaxTruePositives(dic, 738, truth, truth, 5, 0.9)
+    assert tp == len(truth) and all(a == b for a, b in matched)
+    shifted = [dict(a, x=(a["x"] + 60) % 247) for a in truth]
+    tp, _ = csc_amd.computeMaxTruePositives(dic, 738, truth, shifted, 5, 0.9)
+    assert tp < len(truth)
+    assert len(csc_amd.getMatchedAtoms(dic, 738, truth, shifted, 5, 0.9)) == len(truth)
+
+
+WORKER = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch.distributed as dist
+rank, world, port, src, dst = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+import csc_amd
+from csc_amd import distributed as D
+from helpers import OracleBank
+from oracle import csc_oracle as O
+# 1. raw gather with uneven shards (7 records over 2 ranks -> 4 + 3)
+lo, hi = D.shard_range(7, rank, world)
+local = (np.arange(lo, hi, dtype=np.uint8)[:, None] * np.ones((1, 5), np.uint8))
+got = D.gather_records(local, 7)
+assert (got is None) == (rank != 0)
+if rank == 0:
+    assert got.shape == (7, 5) and (got[:, 0] == np.arange(7)).all()
+# 2. the sparVar pipeline: every rank solves its slice, rank 0 writes the JSON
+d = csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.005), np.arange(0.010, 0.036, 0.002), [1])
+bank = OracleBank(O.canonical_dictionary())
+d.device_bank = lambda: bank
+d.mmpdfSparVarPipelineFromDB(src, dst, 1, 3, 0.8, 3, 5)
+json.dump({"rank": rank, "calls": bank.calls}, open(dst + f".rank{rank}", "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_pipeline_sharded_gloo_world2(golden_signals, tmp_path):
+    """world_size 2 (gloo): shards [0,3) / [3,5), one gather, JSON written by rank 0 only and equal to
+    the single-process result."""
+    idx = list(range(0, 64, 4))[:5]
+    src, dst = str(tmp_path / "db.json"), str(tmp_path / "out.json")
+    _write_db(src, golden_signals, idx)
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port, src, dst],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    calls = [json.load(open(dst + f".rank{r}"))["calls"] for r in range(2)]
+    assert calls == [[3], [2]]
+    out = json.load(open(dst))
+    assert [m["id"] for m in out["mmp"]] == idx
+    ref = load_json("sparvar.json")["c3_B3_K5_thr0.8"]
+    for got, r in zip(out["mmp"], ref[:5]):
+        check_sparvar(got, r)
