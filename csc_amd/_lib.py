@@ -25,6 +25,10 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `make -C csc_amd/csrc` "
                 "(or `python -c 'import __graft_entry__ as g; g.build()'`). csc_amd has no CPU fallback.")
+        # torch first: it carries its own HIP runtime (torch/lib/libamdhip64.so); loading ours before it
+        # would bind libcsc_hip.so to a second runtime under /opt/rocm that shares no device state
+        # (streams, allocations) with the tensors we are handed -> "no ROCm-capable device".
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         vp, i32, sz, dbl = C.c_void_p, C.c_int, C.c_size_t, C.c_double
         sig = {

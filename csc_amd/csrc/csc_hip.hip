@@ -645,6 +645,15 @@ __global__ void reduce_kernel(int S, int Kmax, int NN, TreeShape ts, const int32
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// hipGetLastError() is sticky per host thread: drop whatever an earlier, unrelated HIP call of the
+// process left behind so a launch is judged by its own status only.
+static inline void clear_stale_error() { (void)hipGetLastError(); }
+static int launch_status(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL((int)e, "%s launch failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
 static int ceil4(int v) { return (v + 3) & ~3; }
 static int ceil8(int v) { return (v + 7) & ~7; }
 static int ceil32(int v) { return (v + 31) & ~31; }
@@ -716,9 +725,10 @@ int csc_sim_words(int N, int L) {
 int csc_bank_pack(const double* d_bank64, int K, int L, float* d_bank32t, void* stream) {
     if (!d_bank64 || !d_bank32t || K <= 0 || L <= 0) FAIL(-1, "csc_bank_pack: bad arguments");
     const size_t total = csc_bank32_elems(K, L);
+    clear_stale_error();
     hipLaunchKernelGGL(bank_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, d_bank64, K, L, ceil32(L), d_bank32t, total);
-    return (int)hipGetLastError();
+    return launch_status("bank_pack_kernel");
 }
 
 int csc_similarity_table(const double* d_bank64, int K, int L, int N, double threshold,
@@ -728,9 +738,10 @@ int csc_similarity_table(const double* d_bank64, int K, int L, int N, double thr
     if (P <= 0) FAIL(-6, "signal length %d shorter than atom length %d", N, L);
     if (K > 65535) FAIL(-7, "K = %d too large for the similarity table launch", K);
     const int W = csc_sim_words(N, L);
+    clear_stale_error();
     hipLaunchKernelGGL(sim_table_kernel, dim3(K, K), dim3(WG), (size_t)2 * L * sizeof(double),
                        (hipStream_t)stream, d_bank64, K, L, P, W, threshold, d_sim_bits);
-    return (int)hipGetLastError();
+    return launch_status("sim_table_kernel");
 }
 
 int csc_correlate(const float* d_bank32t, int K, int L, const double* d_signals, int B, int N,
@@ -743,10 +754,11 @@ int csc_correlate(const float* d_bank32t, int K, int L, const double* d_signals,
     const int R32 = CSC_TILE_ROWS * ((P + CSC_TILE_ROWS - 1) / CSC_TILE_ROWS) + Lp + 4;
     const size_t lds = (size_t)ceil4(R32) * 4 + 2 * SLAB * CSC_TILE_COLS * 4;
     if (lds > 160 * 1024) FAIL(-8, "signal too long for the LDS-resident correlation (%zu B)", lds);
+    clear_stale_error();
     hipFuncSetAttribute((const void*)correlate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(correlate_kernel, dim3(B), dim3(WG), lds, (hipStream_t)stream, d_bank32t, K, L, Lp,
                        d_signals, N, P, d_corr);
-    return (int)hipGetLastError();
+    return launch_status("correlate_kernel");
 }
 
 int csc_tree_nodes(int max_sparsity, int connections, int branches, int* level_sizes) {
@@ -776,6 +788,7 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
     const int NN = make_shape(max_sparsity, connections, branches, &ts);
     if (NN < 0) return NN;
     const int P = N - L + 1;
+    if (S == 0) return 0;
     if (!d_bank32t || !d_bank64 || !d_signals || !d_node_pos || !d_node_atom || !d_node_mse)
         FAIL(-1, "csc_mmpdf_batch: null pointer");
     if (connections > 1 && !d_sim_bits) FAIL(-1, "csc_mmpdf_batch: similarity table required when connections > 1");
@@ -794,6 +807,7 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
     const size_t lds = level_lds_bytes(N, Lp);
     if (lds > 80 * 1024) FAIL(-8, "signal too long for the LDS-resident node kernel (%zu B)", lds);
     if ((size_t)K * W * 4 > 2 * SLAB * CSC_TILE_COLS * 4) FAIL(-8, "similarity row does not fit the slab buffer");
+    clear_stale_error();
     hipFuncSetAttribute((const void*)mmp_level_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 
     double* ws[2] = {static_cast<double*>(d_workspace), static_cast<double*>(d_workspace) + need / 16};
@@ -836,6 +850,7 @@ int csc_project_batch(const double* d_bank64, int K, int L, const double* d_sign
     if (M == 0) return 0;
     const size_t lds = (size_t)((N + 1) & ~1) * 8 + sizeof(SmallLds);
     if (lds > 64 * 1024) FAIL(-8, "signal too long for the LDS-resident projection (%zu B)", lds);
+    clear_stale_error();
     hipLaunchKernelGGL(project_kernel, dim3((unsigned)M), dim3(WG), lds, (hipStream_t)stream, d_bank64, K, L, P,
                        d_signals, N, d_sig_index, d_support, kmax, d_coef, d_mse, d_approx, d_stats);
     hipError_t e = hipGetLastError();
