@@ -7,32 +7,40 @@
 //      operand is the Hankel matrix A[p][l] = r[p + l], read straight out of the LDS-resident
 //      residual (one ds_read_b32 per fragment, no materialisation); the atom bank streams
 //      L2 -> LDS in 32-row slabs; 4 waves x (4 x 9) v_mfma_f32_16x16x4_f32 accumulators keep the
-//      whole matrix in registers (reference: src/csc/dictionary.py:395-407, src/csc/mmp.py:69),
+//      whole matrix in registers (reference: src/csc/dictionary.py:395-407, src/csc/mmp.py:69).
+//      The bank's columns are sorted by support so that (32-row x 16-atom) blocks that hold only
+//      the atoms' zero padding are neither staged nor multiplied (exact: they contribute +0),
 //   3. selects the node's children with the reference's multiplicative sibling suppression
 //      (src/csc/mmp.py:210-231): fp32 arg-max by wavefront reductions, then every entry within a
 //      guaranteed fp32 error band of the maximum is re-scored in fp64 so the selection equals the
 //      float64 reference's,
-//   4. solves each child's least squares on its support with an fp64 Gram / Cholesky in LDS
-//      (replaces lsqr on the masked operator, src/csc/mmp.py:65-68) and writes the child's
-//      residual, MSE, coefficients and (pos, atom).
+//   4. solves each child's least squares on its support in fp64 by extending the parent's Cholesky
+//      factor with one row (replaces lsqr on the masked operator, src/csc/mmp.py:65-68) and writes
+//      the child's residual, factor, MSE, coefficients and (pos, atom).
 // Levels are launched one after the other (level-synchronous frontier, closed form of
-// src/csc/mmp.py:303-313,388-424); csc_reduce_kernel then extracts the per-sparsity winners
+// src/csc/mmp.py:303-313,388-424); reduce_kernel then extracts the per-sparsity winners
 // (src/csc/mmp.py:577-606, 458-467).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 
 #include "../../include/csc_hip.h"
 
 #define WG 256
-#define SLAB 32
-#define MT 4
-#define NT 9
+#define SLAB 32                        // bank rows per LDS slab
+#define MT 4                           // 16-row MFMA tiles per wave
+#define NT 9                           // 16-column MFMA tiles per workgroup (144 atoms)
+#define BLKF (SLAB * 16)               // floats of one (slab, column-tile) block, contiguous in memory
+#define SLABF (NT * BLKF)              // floats of one slab of a 144-atom bank tile
+#define MAX_SLABS 64                   // L <= 2048
+#define META_INTS (CSC_TILE_COLS + MAX_SLABS)   // per bank tile: perm[144] + slab masks[64]
 #define CAND_CAP 64
 #define SUPP_BITS 0x7fc00001u          // quiet-NaN payload marking a suppressed entry (value 0)
 #define KMAX CSC_MAX_SPARSITY
+#define TRI(n) ((n) * ((n) + 1) / 2)
 #define DELTA_REL 6.103515625e-05f      // 2^-14: fp32 candidate band, in units of ||residual||
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -47,12 +55,14 @@ struct TreeShape {
 };
 
 struct LevelArgs {
-    const float* bank32t; const double* bank64; const uint32_t* sim_bits;
+    const float* bank32t; const int32_t* meta; const double* bank64; const uint32_t* sim_bits;
     int K, L, Lp, N, P, W;
     int depth;            // level d of the parents expanded by this launch
     int Kmax, connections, NN;
-    const double* resid_in;   // d == 0: signals [S][N]; else [S][F[d]][N]
-    double* resid_out;        // [S][F[d+1]][N] or nullptr (children are final leaves)
+    int NS;               // doubles per node in the workspace: N residual + TRI(Kmax) Cholesky factor
+    int stagger_ticks;    // > 0: initial phase offset between the two workgroups of a CU (100 MHz ticks)
+    const double* resid_in;   // d == 0: signals [S][N]; else [S][F[d]][NS]
+    double* resid_out;        // [S][F[d+1]][NS] or nullptr (children are final leaves)
     int32_t* node_pos; int32_t* node_atom; double* node_mse; double* node_coef;
     int32_t* stats;
     TreeShape ts;
@@ -64,6 +74,11 @@ struct LevelArgs {
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double half_wave_sum(double v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
@@ -81,33 +96,39 @@ __device__ __forceinline__ int wave_min(int v) {
 }
 __device__ __forceinline__ bool is_supp(float x) { return __float_as_uint(x) == SUPP_BITS; }
 
-// Full (256 x 144) x Lp correlation tile on v_mfma_f32_16x16x4_f32.
-//   bank   : global, [Lr][144] f32 column tile of the packed bank, Lr = ceil32(L) rows allocated,
-//            rows >= L are zero; Lp = ceil8(L) rows are multiplied
+// ------------------------------------------------------------------------------------------------
+// (256 x 144) x Lp correlation tile on v_mfma_f32_16x16x4_f32
+// ------------------------------------------------------------------------------------------------
+//   tile   : global, packed bank tile [nslab][NT][SLAB][16] f32 (rows >= L and pad columns zero)
+//   masks  : LDS, masks[s] bit ni set <=> block (slab s, column tile ni) holds a non-zero
 //   r32row : LDS, &r32[row_block + 64*wave + (lane & 15) + (lane >> 4)]
-//   slab   : LDS, 2 x SLAB x 144 floats
+//   slab   : LDS, 2 x SLABF floats
 // acc[mi][ni][reg] = C[row = 64*wave + 16*mi + 4*(lane>>4) + reg][col = 16*ni + (lane&15)]
 //
-// Staging: each 32-row slab (18 KiB) is copied global -> LDS by 18 global_load_lds_dwordx4
-// wave-instructions (1 KiB each, no VGPRs), issued before the MFMAs of the previous slab and
-// retired by the vmcnt(0) the compiler places in front of the slab's closing barrier.
+// Staging: the blocks of slab s+1 are copied global -> LDS by global_load_lds_dwordx4 (1 KiB per
+// wave-instruction, no VGPRs), issued before the MFMAs of slab s and retired by the fence of the
+// slab's closing barrier.  Column tiles are sorted by support, so for slab s only tiles
+// ni >= ctz(masks[s]) are staged and multiplied.
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ void stage_slab(const float* gsrc, float* ldst, int wave, int lane) {
-    constexpr int PIECES = SLAB * CSC_TILE_COLS * 4 / 1024;           // 18
+__device__ __forceinline__ void stage_blocks(const float* gslab, float* lslab, int ni0, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < (PIECES + 3) / 4; ++i) {
-        const int piece = wave + 4 * i;                               // wave-uniform
-        if (piece < PIECES)
-            __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + piece * 256 + lane * 4),
-                                             (lptr_t)(ldst + piece * 256), 16, 0, 0);
+    for (int i = 0; i < (2 * NT + 3) / 4; ++i) {
+        const int piece = 2 * ni0 + wave + 4 * i;                     // wave-uniform, 1 KiB each
+        if (piece < 2 * NT)
+            __builtin_amdgcn_global_load_lds((gptr_t)(gslab + piece * 256 + lane * 4),
+                                             (lptr_t)(lslab + piece * 256), 16, 0, 0);
     }
 }
 
-__device__ __forceinline__ void corr_tile_gemm(const float* __restrict__ bank, int Lp,
-                                               const float* r32row, float* slab,
-                                               f32x4 (&acc)[MT][NT]) {
+// One slab = 32 bank rows = 8 k-steps.  The wave's Hankel fragments of the slab are 20 distinct LDS
+// words (fragment (mi, ks) is word 16*mi + 4*ks of the residual window), loaded once and reused by
+// every column tile; the B fragments of column tile ni+1 are prefetched under the 32 MFMAs of tile ni.
+// Column tiles below ni0 (all zero padding in this slab) are skipped with wave-uniform branches; the
+// 4 accumulators of a column tile rotate, so no MFMA waits on its own result.
+__device__ __forceinline__ void corr_tile_gemm(const float* __restrict__ tile, const uint32_t* masks, int nslab,
+                                               const float* r32row, float* slab, f32x4 (&acc)[MT][NT]) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
@@ -116,77 +137,104 @@ __device__ __forceinline__ void corr_tile_gemm(const float* __restrict__ bank, i
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nslab = (Lp + SLAB - 1) / SLAB;
-    stage_slab(bank, slab, wave, lane);
+    uint32_t m = __builtin_amdgcn_readfirstlane(masks[0]);
+    if (m) stage_blocks(tile, slab, __builtin_ctz(m), wave, lane);
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
-        if (s + 1 < nslab)
-            stage_slab(bank + (size_t)(s + 1) * SLAB * CSC_TILE_COLS,
-                       slab + ((s + 1) & 1) * (SLAB * CSC_TILE_COLS), wave, lane);
-        const float* sb = slab + (s & 1) * (SLAB * CSC_TILE_COLS) + lq * CSC_TILE_COLS + lr;
-        const float* ra = r32row + s * SLAB;
-        const int nks = min(SLAB, Lp - s * SLAB) >> 2;                // even (Lp % 8 == 0)
-        // two k-steps per iteration with ping-pong fragments: the LDS reads of the next k-step are
-        // issued in front of the 36 MFMAs of the current one
-        float a0[MT], b0[NT], a1[MT], b1[NT];
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) a0[mi] = ra[16 * mi];
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) b0[ni] = sb[16 * ni];
-#pragma unroll 1
-        for (int ks = 0; ks < nks; ks += 2) {
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) a1[mi] = ra[16 * mi + 4 * (ks + 1)];
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) b1[ni] = sb[4 * (ks + 1) * CSC_TILE_COLS + 16 * ni];
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NT; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
-            // the 7 LDS reads of the next k-step go out between the first MFMAs
-#pragma unroll
-            for (int g = 0; g < 7; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 22, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            const int kn = min(ks + 2, nks - 1);
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) a0[mi] = ra[16 * mi + 4 * kn];
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) b0[ni] = sb[4 * kn * CSC_TILE_COLS + 16 * ni];
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NT; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 7; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 22, 0);
-            __builtin_amdgcn_sched_barrier(0);
+        uint32_t mn = 0;
+        if (s + 1 < nslab) {
+            mn = __builtin_amdgcn_readfirstlane(masks[s + 1]);
+            if (mn) stage_blocks(tile + (size_t)(s + 1) * SLABF, slab + ((s + 1) & 1) * SLABF, __builtin_ctz(mn), wave, lane);
         }
+        if (m) {
+            const int ni0 = __builtin_ctz(m);
+            const float* ra = r32row + s * SLAB;
+            const float* sb = slab + (s & 1) * SLABF + lq * 16 + lr;
+            float af[4 * MT + 4], bf[2][8];
+#pragma unroll
+            for (int q = 0; q < 4 * MT + 4; ++q) af[q] = ra[4 * q];
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                if (ni >= ni0) {
+                    if (ni == ni0) {
+#pragma unroll
+                        for (int ks = 0; ks < 8; ++ks) bf[ni & 1][ks] = sb[ni * BLKF + 64 * ks];
+                    }
+                    if (ni + 1 < NT) {
+#pragma unroll
+                        for (int ks = 0; ks < 8; ++ks) bf[(ni + 1) & 1][ks] = sb[(ni + 1) * BLKF + 64 * ks];
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                        for (int mi = 0; mi < MT; ++mi)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * mi + ks], bf[ni & 1][ks],
+                                                                              acc[mi][ni], 0, 0, 0);
+                }
+            }
+        }
+        m = mn;
         __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// bank packing: [K][L] f64 -> [ceil(K/144)][Lp][144] f32 (zero padded)
+// bank packing: [K][L] f64 -> column tiles sorted by support, blocked [tile][slab][ni][32][16] f32
 // ------------------------------------------------------------------------------------------------
-__global__ void bank_pack_kernel(const double* __restrict__ bank64, int K, int L, int Lp,
-                                 float* __restrict__ out, size_t total) {   // Lp = allocated rows
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// keys[k] = first non-zero row of atom k (L for an all-zero atom); parked in the data region that
+// bank_pack_kernel overwrites afterwards
+__global__ void bank_keys_kernel(const double* __restrict__ bank64, int K, int L, int32_t* __restrict__ keys) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    int first = L;
+    for (int l = 0; l < L; ++l)
+        if (bank64[(size_t)k * L + l] != 0.0) { first = l; break; }
+    keys[k] = first;
+}
+
+// sorted position: later first row (= narrower centred support) first, index as tie-break; the
+// ntile*144 - K padding columns go in front.  perm[t][c] = atom of column c of tile t, or -1.
+__global__ void bank_rank_kernel(const int32_t* __restrict__ keys, int K, int npad, int32_t* __restrict__ meta) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const int key = keys[k];
+    int rank = 0;
+    for (int j = 0; j < K; ++j) {
+        const int kj = keys[j];
+        rank += (kj > key || (kj == key && j < k)) ? 1 : 0;
+    }
+    const int col = npad + rank;
+    meta[(col / CSC_TILE_COLS) * META_INTS + col % CSC_TILE_COLS] = k;
+    if (k < npad) meta[k] = -1;                                       // pads sit in tile 0
+}
+
+__global__ void bank_pack_kernel(const double* __restrict__ bank64, int K, int L, int nslab,
+                                 const int32_t* __restrict__ meta, float* __restrict__ out, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int col = (int)(i % CSC_TILE_COLS);
-    const size_t t = i / CSC_TILE_COLS;
-    const int l = (int)(t % Lp);
-    const int chunk = (int)(t / Lp);
-    const int k = chunk * CSC_TILE_COLS + col;
-    out[i] = (k < K && l < L) ? (float)bank64[(size_t)k * L + l] : 0.f;
+    const int col16 = (int)(i & 15), row = (int)((i >> 4) & (SLAB - 1));
+    size_t t = i / BLKF;
+    const int ni = (int)(t % NT); t /= NT;
+    const int slab = (int)(t % nslab);
+    const int tile = (int)(t / nslab);
+    const int k = meta[tile * META_INTS + 16 * ni + col16];
+    const int l = slab * SLAB + row;
+    out[i] = (k >= 0 && l < L) ? (float)bank64[(size_t)k * L + l] : 0.f;
+}
+
+// masks[tile][slab]: bit ni set <=> the block holds a non-zero value
+__global__ void bank_mask_kernel(const float* __restrict__ tiles, int nslab, int32_t* __restrict__ meta) {
+    __shared__ uint32_t m;
+    const int slab = blockIdx.x, tile = blockIdx.y;
+    if (threadIdx.x == 0) m = 0;
+    __syncthreads();
+    const float* blk = tiles + ((size_t)tile * nslab + slab) * SLABF;
+    uint32_t mine = 0;
+    for (int i = threadIdx.x; i < SLABF; i += blockDim.x)
+        if (blk[i] != 0.f) mine |= 1u << (i / BLKF);
+    if (mine) atomicOr(&m, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) meta[tile * META_INTS + CSC_TILE_COLS + slab] = (int32_t)m;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -236,24 +284,32 @@ __global__ __launch_bounds__(WG) void sim_table_kernel(const double* __restrict_
 // ------------------------------------------------------------------------------------------------
 // stand-alone batched correlation (API parity: computeCorrelations)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG, 2) void correlate_kernel(const float* __restrict__ bank32t, int K, int L,
+__global__ __launch_bounds__(WG, 2) void correlate_kernel(const float* __restrict__ bank32t,
+                                                          const int32_t* __restrict__ meta, int K, int L,
                                                           int Lp, const double* __restrict__ signals,
                                                           int N, int P, float* __restrict__ out) {
     extern __shared__ float lds[];
-    const int R32 = CSC_TILE_ROWS * ((P + CSC_TILE_ROWS - 1) / CSC_TILE_ROWS) + Lp + 4;
+    __shared__ uint32_t masks[MAX_SLABS];
+    const int R32 = CSC_TILE_ROWS * ((P + CSC_TILE_ROWS - 1) / CSC_TILE_ROWS) + Lp + 4;   // Lp = whole slabs
     float* slab = lds;
-    float* r32 = lds + 2 * SLAB * CSC_TILE_COLS;
+    float* r32 = lds + 2 * SLABF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const size_t b = blockIdx.x;
     for (int i = tid; i < R32; i += WG) r32[i] = (i < N) ? (float)signals[b * N + i] : 0.f;
-    __syncthreads();
-    const int nchunk = (K + CSC_TILE_COLS - 1) / CSC_TILE_COLS;
+    const int ntile = (K + CSC_TILE_COLS - 1) / CSC_TILE_COLS;
+    const int nslab = (L + SLAB - 1) / SLAB;
     const int nrb = (P + CSC_TILE_ROWS - 1) / CSC_TILE_ROWS;
-    for (int rb = 0; rb < nrb; ++rb)
-        for (int ch = 0; ch < nchunk; ++ch) {
+    for (int tl = 0; tl < ntile; ++tl) {
+        __syncthreads();
+        if (tid < nslab) masks[tid] = (uint32_t)meta[tl * META_INTS + CSC_TILE_COLS + tid];
+        int permv[NT];
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) permv[ni] = meta[tl * META_INTS + 16 * ni + lr];
+        __syncthreads();
+        for (int rb = 0; rb < nrb; ++rb) {
             f32x4 acc[MT][NT];
-            corr_tile_gemm(bank32t + (size_t)ch * ((L + 31) & ~31) * CSC_TILE_COLS, Lp,
+            corr_tile_gemm(bank32t + (size_t)tl * nslab * SLABF, masks, nslab,
                            r32 + rb * CSC_TILE_ROWS + 64 * wave + lr + lq, slab, acc);
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
@@ -262,26 +318,21 @@ __global__ __launch_bounds__(WG, 2) void correlate_kernel(const float* __restric
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
                         const int p = rb * CSC_TILE_ROWS + 64 * wave + 16 * mi + 4 * lq + rg;
-                        const int k = ch * CSC_TILE_COLS + 16 * ni + lr;
-                        if (p < P && k < K) out[(b * P + p) * K + k] = acc[mi][ni][rg];
+                        if (p < P && permv[ni] >= 0) out[(b * P + p) * K + permv[ni]] = acc[mi][ni][rg];
                     }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// the level kernel
+// batched projection on given supports (API parity: getSignalProjectionFromAtoms)
 // ------------------------------------------------------------------------------------------------
-struct SmallLds {
+struct ProjLds {
     double G[KMAX][KMAX + 1];
-    double b[KMAX], x[KMAX], coefpar[KMAX];
-    double cand_val[CAND_CAP];
+    double b[KMAX], x[KMAX];
     double wsum[WG / 64];
-    int cand_idx[CAND_CAP];
     int sup_pos[KMAX], sup_atom[KMAX];
-    float wmax[WG / 64];
-    int widx[WG / 64], wsupp[WG / 64];
-    int cand_cnt, chosen, i32, bad;
-    float m32;
+    int cand_cnt, bad;
 };
 
 // Least squares of the LDS-resident target r64 on the placed atoms sup_pos/sup_atom[0..n): fp64 Gram
@@ -290,7 +341,7 @@ struct SmallLds {
 // (src/csc/mmp.py:65-67, src/csc/dictionary.py:471,528).  A column that is numerically dependent on
 // the earlier ones (an activation listed twice) is decoupled and gets coefficient 0; sl->bad flags it.
 // Contains workgroup barriers: every thread of the workgroup must call it.
-__device__ __forceinline__ void support_ls(SmallLds* sl, int n, const double* r64,
+__device__ __forceinline__ void support_ls(ProjLds* sl, int n, const double* r64,
                                            const double* __restrict__ bank64, int L) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int npair = n * (n + 1) / 2;
@@ -364,7 +415,7 @@ __global__ __launch_bounds__(WG) void project_kernel(const double* __restrict__ 
                                                      double* __restrict__ approx, int32_t* stats) {
     extern __shared__ double lds_raw[];
     double* r64 = lds_raw;                                            // [N]
-    SmallLds* sl = reinterpret_cast<SmallLds*>(r64 + ((N + 1) & ~1));
+    ProjLds* sl = reinterpret_cast<ProjLds*>(r64 + ((N + 1) & ~1));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t m = blockIdx.x;
     const size_t s = sig_index ? (size_t)sig_index[m] : m;
@@ -402,6 +453,26 @@ __global__ __launch_bounds__(WG) void project_kernel(const double* __restrict__ 
     if (coef && tid < kmax) coef[m * kmax + tid] = tid < n ? sl->x[tid] : 0.0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// the level kernel
+// ------------------------------------------------------------------------------------------------
+struct NodeLds {
+    double Lf[TRI(KMAX)];          // parent's Cholesky factor, packed lower triangle, row i at TRI(i)
+    double g[KMAX + 2];            // <a_new, a_q> q < d | ||a_new||^2 | <a_new, r_parent>
+    double y[KMAX + 1];            // new factor row (y_0..y_{d-1}, l_dd)
+    double x[KMAX + 1];            // LS solution of the parent residual on the child's support
+    double coefpar[KMAX];
+    double cand_val[CAND_CAP];
+    double wsum[WG / 64];
+    int cand_idx[CAND_CAP];
+    int sup_pos[KMAX + 1], sup_atom[KMAX + 1];
+    uint32_t masks[MAX_SLABS];
+    float wmax[WG / 64];
+    int widx[WG / 64], wsupp[WG / 64];
+    int cand_cnt, chosen, i32, bad, odd_slot;
+    float m32;
+};
+
 __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     extern __shared__ double lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -411,11 +482,11 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     // ---- LDS carve-up ---------------------------------------------------------------------------
     const int Npad = (N + 3) & ~3;
     const int R32 = CSC_TILE_ROWS + Lp + 4;
-    float* slab = reinterpret_cast<float*>(lds_raw);                  // [2][SLAB][144]
+    float* slab = reinterpret_cast<float*>(lds_raw);                  // [2][SLABF]
     uint32_t* simrow = reinterpret_cast<uint32_t*>(slab);             // aliases the slabs
-    double* r64 = lds_raw + (2 * SLAB * CSC_TILE_COLS) / 2;           // [Npad]
+    double* r64 = lds_raw + SLABF;                                    // [Npad]   (2*SLABF floats = SLABF doubles)
     float* r32 = reinterpret_cast<float*>(r64 + Npad);                // [R32]
-    SmallLds* sl = reinterpret_cast<SmallLds*>(r32 + ((R32 + 3) & ~3));
+    NodeLds* sl = reinterpret_cast<NodeLds*>(r32 + ((R32 + 3) & ~3));
 
     // ---- which node ------------------------------------------------------------------------------
     const int Fd = a.ts.F[d], Fc = a.ts.F[d + 1];
@@ -426,10 +497,20 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     for (int r = 0; r < a.connections; ++r) {
         if ((long long)j + (long long)r * stride < Fc) ++nch; else break;
     }
-    const int k_child = d + 1;                                        // support size of the children
 
-    // ---- residual -> LDS, norm ---------------------------------------------------------------------
-    const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)N);
+    // ---- optional start-up stagger: the two workgroups that share a CU at launch would otherwise
+    //      run their MFMA phases and their selection phases in lock-step ---------------------------------
+    if (a.stagger_ticks > 0 && blockIdx.x < 2 * 256) {
+        if (tid == 0) sl->odd_slot = (int)(__builtin_amdgcn_s_getreg(63492) & 1u);   // HW_ID.WAVE_ID bit 0
+        __syncthreads();
+        if (sl->odd_slot) {
+            const unsigned long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < (unsigned long long)a.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+        }
+    }
+
+    // ---- residual -> LDS, norm; ancestors, parent's factor, bank metadata -----------------------------
+    const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
     double ss = 0.0;
     for (int i = tid; i < Npad; i += WG) {
         const double v = (i < N) ? rin[i] : 0.0;
@@ -437,7 +518,6 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
         ss = fma(v, v, ss);
     }
     for (int i = tid; i < R32; i += WG) r32[i] = (i < N) ? (float)rin[i] : 0.f;
-    // ancestors (root -> parent) and the parent's coefficients, loaded in parallel
     if (tid < d) {
         const int e = tid + 1;                                        // level of this ancestor
         const size_t id = s * a.NN + a.ts.off[e] + (j % a.ts.pw[e]);
@@ -445,6 +525,8 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
         sl->sup_atom[tid] = a.node_atom[id];
         sl->coefpar[tid] = a.node_coef ? a.node_coef[(s * a.NN + a.ts.off[d] + j) * (size_t)a.Kmax + tid] : 0.0;
     }
+    if (tid >= 64 && tid < 64 + TRI(d)) sl->Lf[tid - 64] = rin[N + tid - 64];
+    if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
     ss = wave_sum(ss);
     if (lane == 0) sl->wsum[wave] = ss;
     __syncthreads();
@@ -453,33 +535,41 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
 
     // ---- correlations on the matrix cores ------------------------------------------------------------
     f32x4 acc[MT][NT];
-    corr_tile_gemm(a.bank32t, Lp, r32 + 64 * wave + lr + lq, slab, acc);
+    corr_tile_gemm(a.bank32t, sl->masks, (L + SLAB - 1) / SLAB, r32 + 64 * wave + lr + lq, slab, acc);
 
+    int permv[NT];                                // atom of this lane's column in tile ni (-1 = padding)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) permv[ni] = a.meta[16 * ni + lr];
     const int prow = 64 * wave + 4 * lq;          // + 16*mi + reg
-    const int base_idx = prow * K + lr;           // + (16*mi + reg)*K + 16*ni
+    const int rowK = prow * K;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg)
-                if (prow + 16 * mi + rg >= P || 16 * ni + lr >= K) acc[mi][ni][rg] = -INFINITY;
+                if (prow + 16 * mi + rg >= P || permv[ni] < 0) acc[mi][ni][rg] = -INFINITY;
 
     // ---- children, one selection round per sibling -------------------------------------------------
     for (int t = 0; t < nch; ++t) {
-        // (a) fp32 maximum (lowest index on ties)
+        // (a) fp32 maximum (lowest flattened index pos*K + atom on ties)
         float bv = -INFINITY;
         int bi = 0x7fffffff;
+        int Ka = K;                                // opaque copy: keeps the 144 flattened indices from being
+        asm volatile("" : "+v"(Ka));               // hoisted out of the sibling loop into registers
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
+            for (int rg = 0; rg < 4; ++rg) {
+                const int rbase = rowK + (16 * mi + rg) * Ka;
 #pragma unroll
                 for (int ni = 0; ni < NT; ++ni) {
                     const float x = acc[mi][ni][rg];
                     const float e = is_supp(x) ? 0.f : x;
-                    if (e > bv) { bv = e; bi = base_idx + (16 * mi + rg) * K + 16 * ni; }
+                    const int idx = rbase + permv[ni];
+                    if (e > bv || (e == bv && idx < bi)) { bv = e; bi = idx; }
                 }
+            }
         wave_argmax(bv, bi);
         if (lane == 0) { sl->wmax[wave] = bv; sl->widx[wave] = bi; }
         __syncthreads();
@@ -496,21 +586,24 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
         const bool zero_band = (0.f >= tau);
         // (b) every unsuppressed entry inside the fp32 error band of the maximum is a candidate
         int first_supp = 0x7fffffff;
+        int Kb = K;
+        asm volatile("" : "+v"(Kb));
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
+            for (int rg = 0; rg < 4; ++rg) {
+                const int rbase = rowK + (16 * mi + rg) * Kb;
 #pragma unroll
                 for (int ni = 0; ni < NT; ++ni) {
                     const float x = acc[mi][ni][rg];
-                    const int idx = base_idx + (16 * mi + rg) * K + 16 * ni;
                     if (is_supp(x)) {
-                        if (zero_band) first_supp = min(first_supp, idx);
+                        if (zero_band) first_supp = min(first_supp, rbase + permv[ni]);
                     } else if (x >= tau) {
                         const int slot = atomicAdd(&sl->cand_cnt, 1);
-                        if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
+                        if (slot < CAND_CAP) sl->cand_idx[slot] = rbase + permv[ni];
                     }
                 }
+            }
         if (zero_band) {
             first_supp = wave_min(first_supp);
             if (lane == 0) sl->wsupp[wave] = first_supp;
@@ -556,21 +649,74 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
         const int jc = j + t * stride;                               // child's index in level d+1
         const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
 
-        // ---- child least squares on its support (fp64 Gram / Cholesky in LDS) ----------------------
-        support_ls(sl, k_child, r64, a.bank64, L);
-        if (tid == 0 && sl->bad && a.stats) atomicAdd(&a.stats[1], 1);
-        // ---- child residual, MSE ------------------------------------------------------------------
-        double* rout = a.resid_out ? a.resid_out + (s * Fc + jc) * (size_t)N : nullptr;
+        // ---- child least squares: one new Gram column (fp64 dots, one per half-wave) ---------------
+        {
+            const int hw = tid >> 5, hl = tid & 31;
+            const double* an = a.bank64 + (size_t)k_sel * L;
+            for (int q = hw; q < d + 2; q += WG / 32) {
+                double v = 0.0;
+                if (q < d) {                                         // <a_new @ p_sel, a_q @ p_q>
+                    const double* aq = a.bank64 + (size_t)sl->sup_atom[q] * L;
+                    const int dp = p_sel - sl->sup_pos[q];           // a_q index = i + dp
+                    const int lo = max(0, -dp), hi = min(L, L - dp);
+                    for (int i = lo + hl; i < hi; i += 32) v = fma(an[i], aq[i + dp], v);
+                } else if (q == d) {                                 // ||a_new||^2
+                    for (int i = hl; i < L; i += 32) v = fma(an[i], an[i], v);
+                } else {                                             // <a_new, r_parent>
+                    for (int i = hl; i < L; i += 32) v = fma(an[i], r64[p_sel + i], v);
+                }
+                v = half_wave_sum(v);
+                if (hl == 0) sl->g[q] = v;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // factor row: Lf y = g, l_dd^2 = g_dd - y.y.  A dead column (an activation selected twice,
+            // src/csc/mmp.py:56 sets the same mask bit again) has diagonal 0 and is skipped everywhere.
+            double yy = 0.0;
+            for (int i = 0; i < d; ++i) {
+                const double dg = sl->Lf[TRI(i) + i];
+                double v = sl->g[i];
+                for (int m = 0; m < i; ++m) v -= sl->Lf[TRI(i) + m] * sl->y[m];
+                v = (dg != 0.0) ? v / dg : 0.0;
+                sl->y[i] = v;
+                yy = fma(v, v, yy);
+            }
+            const double gdd = sl->g[d], sdd = gdd - yy;
+            const bool bad = !(sdd > 1e-13 * gdd);
+            double xd = 0.0;
+            if (bad) {
+                for (int i = 0; i < d; ++i) sl->y[i] = 0.0;
+                sl->y[d] = 0.0;
+            } else {
+                sl->y[d] = sqrt(sdd);
+                xd = sl->g[d + 1] / sdd;                             // (beta / l_dd) / l_dd
+            }
+            // Lf^T x = z with z = (0, ..., 0, beta / l_dd): the parent residual is orthogonal to the
+            // ancestors' atoms, so only the new right-hand side entry is non-zero
+            sl->x[d] = xd;
+            for (int r = d - 1; r >= 0; --r) {
+                const double dg = sl->Lf[TRI(r) + r];
+                double v = -sl->y[r] * xd;
+                for (int m = r + 1; m < d; ++m) v -= sl->Lf[TRI(m) + r] * sl->x[m];
+                sl->x[r] = (dg != 0.0) ? v / dg : 0.0;
+            }
+            if (bad && a.stats) atomicAdd(&a.stats[1], 1);
+        }
+        __syncthreads();
+        // ---- child residual, factor, MSE ------------------------------------------------------------
+        double* rout = a.resid_out ? a.resid_out + (s * Fc + jc) * (size_t)a.NS : nullptr;
         double cs = 0.0;
         for (int n = tid; n < N; n += WG) {
             double v = r64[n];
-            for (int i = 0; i < k_child; ++i) {
+            for (int i = 0; i <= d; ++i) {
                 const int o = n - sl->sup_pos[i];
                 if (o >= 0 && o < L) v = fma(-sl->x[i], a.bank64[(size_t)sl->sup_atom[i] * L + o], v);
             }
             if (rout) rout[n] = v;
             cs = fma(v, v, cs);
         }
+        if (rout && tid < TRI(d + 1)) rout[N + tid] = tid < TRI(d) ? sl->Lf[tid] : sl->y[tid - TRI(d)];
         cs = wave_sum(cs);
         if (lane == 0) sl->wsum[wave] = cs;
         __syncthreads();
@@ -581,13 +727,13 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
         }
         if (a.node_coef && tid < a.Kmax)
             a.node_coef[cid * a.Kmax + tid] =
-                tid < k_child ? sl->x[tid] + (tid < d ? sl->coefpar[tid] : 0.0) : 0.0;
+                tid <= d ? sl->x[tid] + (tid < d ? sl->coefpar[tid] : 0.0) : 0.0;
 
         // ---- suppress the chosen atom's similarity disk for the next sibling ----------------------
         if (t + 1 < nch) {
-            const int W = a.W;
+            const int W = a.W, W1 = a.W + 1;                         // LDS rows padded by one word
             const uint32_t* g = a.sim_bits + (size_t)k_sel * K * W;
-            for (int i = tid; i < K * W; i += WG) simrow[i] = g[i];
+            for (int i = tid; i < K * W; i += WG) simrow[(i / W) * W1 + (i % W)] = g[i];
             __syncthreads();
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
@@ -595,10 +741,10 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
                 for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
-                        const int p = prow + 16 * mi + rg, k = 16 * ni + lr;
-                        if (p < P && k < K) {
+                        const int p = prow + 16 * mi + rg, k = permv[ni];
+                        if (p < P && k >= 0) {
                             const int dpi = p - p_sel + P - 1;
-                            if ((simrow[k * W + (dpi >> 5)] >> (dpi & 31)) & 1u)
+                            if ((simrow[k * W1 + (dpi >> 5)] >> (dpi & 31)) & 1u)
                                 acc[mi][ni][rg] = __uint_as_float(SUPP_BITS);
                         }
                     }
@@ -656,7 +802,12 @@ static int launch_status(const char* what) {
 
 static int ceil4(int v) { return (v + 3) & ~3; }
 static int ceil8(int v) { return (v + 7) & ~7; }
-static int ceil32(int v) { return (v + 31) & ~31; }
+static int n_tiles(int K) { return (K + CSC_TILE_COLS - 1) / CSC_TILE_COLS; }
+static int n_slabs(int L) { return (L + SLAB - 1) / SLAB; }
+static size_t tile_floats(int K, int L) { return (size_t)n_tiles(K) * n_slabs(L) * SLABF; }
+static const int32_t* bank_meta(const float* d_bank32t, int K, int L) {
+    return reinterpret_cast<const int32_t*>(d_bank32t + tile_floats(K, L));
+}
 
 static int make_shape(int Kmax, int c, int B, TreeShape* ts) {
     if (Kmax < 1 || Kmax > KMAX) FAIL(-2, "max_sparsity %d outside [1, %d]", Kmax, KMAX);
@@ -681,7 +832,17 @@ static int make_shape(int Kmax, int c, int B, TreeShape* ts) {
 static size_t level_lds_bytes(int N, int Lp) {
     const int Npad = ceil4(N);
     const int R32 = CSC_TILE_ROWS + Lp + 4;
-    return (size_t)Npad * 8 + sizeof(SmallLds) + (size_t)ceil4(R32) * 4 + 2 * SLAB * CSC_TILE_COLS * 4;
+    return (size_t)Npad * 8 + sizeof(NodeLds) + (size_t)ceil4(R32) * 4 + 2 * SLABF * 4;
+}
+
+static int stagger_ticks() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CSC_STAGGER_US");
+        v = e ? atoi(e) * 100 : 0;                                    // wall_clock64 runs at 100 MHz
+        if (v < 0 || v > 100000) v = 0;
+    }
+    return v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -713,7 +874,7 @@ const char* csc_last_error(void) { return g_err; }
 
 size_t csc_bank32_elems(int K, int L) {
     if (K <= 0 || L <= 0) return 0;
-    return (size_t)((K + CSC_TILE_COLS - 1) / CSC_TILE_COLS) * ceil32(L) * CSC_TILE_COLS;
+    return tile_floats(K, L) + (size_t)n_tiles(K) * META_INTS;
 }
 
 int csc_sim_words(int N, int L) {
@@ -724,11 +885,19 @@ int csc_sim_words(int N, int L) {
 
 int csc_bank_pack(const double* d_bank64, int K, int L, float* d_bank32t, void* stream) {
     if (!d_bank64 || !d_bank32t || K <= 0 || L <= 0) FAIL(-1, "csc_bank_pack: bad arguments");
-    const size_t total = csc_bank32_elems(K, L);
+    if (n_slabs(L) > MAX_SLABS) FAIL(-8, "atom length %d exceeds %d", L, MAX_SLABS * SLAB);
+    const size_t total = tile_floats(K, L);
+    const int ntile = n_tiles(K), nslab = n_slabs(L), npad = ntile * CSC_TILE_COLS - K;
+    int32_t* meta = reinterpret_cast<int32_t*>(d_bank32t + total);
+    int32_t* keys = reinterpret_cast<int32_t*>(d_bank32t);           // parked in the data region
+    hipStream_t st = (hipStream_t)stream;
     clear_stale_error();
-    hipLaunchKernelGGL(bank_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, d_bank64, K, L, ceil32(L), d_bank32t, total);
-    return launch_status("bank_pack_kernel");
+    hipLaunchKernelGGL(bank_keys_kernel, dim3((K + 255) / 256), dim3(256), 0, st, d_bank64, K, L, keys);
+    hipLaunchKernelGGL(bank_rank_kernel, dim3((K + 255) / 256), dim3(256), 0, st, keys, K, npad, meta);
+    hipLaunchKernelGGL(bank_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_bank64, K, L,
+                       nslab, meta, d_bank32t, total);
+    hipLaunchKernelGGL(bank_mask_kernel, dim3(nslab, ntile), dim3(256), 0, st, d_bank32t, nslab, meta);
+    return launch_status("bank_pack kernels");
 }
 
 int csc_similarity_table(const double* d_bank64, int K, int L, int N, double threshold,
@@ -749,15 +918,16 @@ int csc_correlate(const float* d_bank32t, int K, int L, const double* d_signals,
     const int P = N - L + 1;
     if (!d_bank32t || !d_signals || !d_corr || K <= 0 || L <= 0 || B < 0) FAIL(-1, "csc_correlate: bad arguments");
     if (P <= 0) FAIL(-6, "signal length %d shorter than atom length %d", N, L);
+    if (n_slabs(L) > MAX_SLABS) FAIL(-8, "atom length %d exceeds %d", L, MAX_SLABS * SLAB);
     if (B == 0) return 0;
-    const int Lp = ceil8(L);
-    const int R32 = CSC_TILE_ROWS * ((P + CSC_TILE_ROWS - 1) / CSC_TILE_ROWS) + Lp + 4;
-    const size_t lds = (size_t)ceil4(R32) * 4 + 2 * SLAB * CSC_TILE_COLS * 4;
-    if (lds > 160 * 1024) FAIL(-8, "signal too long for the LDS-resident correlation (%zu B)", lds);
+    const int Lp = n_slabs(L) * SLAB;                      // residual window zero-padded to whole slabs
+    const int R32 = CSC_TILE_ROWS * ((P + CSC_TILE_ROWS - 1) / CSC_TILE_ROWS) + Lp + 4;   // Lp = whole slabs
+    const size_t lds = (size_t)ceil4(R32) * 4 + 2 * SLABF * 4;
+    if (lds > 150 * 1024) FAIL(-8, "signal too long for the LDS-resident correlation (%zu B)", lds);
     clear_stale_error();
     hipFuncSetAttribute((const void*)correlate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(correlate_kernel, dim3(B), dim3(WG), lds, (hipStream_t)stream, d_bank32t, K, L, Lp,
-                       d_signals, N, P, d_corr);
+    hipLaunchKernelGGL(correlate_kernel, dim3(B), dim3(WG), lds, (hipStream_t)stream, d_bank32t,
+                       bank_meta(d_bank32t, K, L), K, L, Lp, d_signals, N, P, d_corr);
     return launch_status("correlate_kernel");
 }
 
@@ -774,7 +944,7 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
     if (make_shape(max_sparsity, connections, branches, &ts) < 0 || S <= 0 || N <= 0) return 0;
     int fmax = 1;
     for (int d = 1; d < max_sparsity; ++d) fmax = ts.F[d] > fmax ? ts.F[d] : fmax;
-    return 2 * (size_t)S * fmax * N * sizeof(double);
+    return 2 * (size_t)S * fmax * (N + TRI(max_sparsity)) * sizeof(double);
 }
 
 int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
@@ -797,16 +967,16 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
     if (K > CSC_TILE_COLS || P > CSC_TILE_ROWS)
         FAIL(-9, "dictionary (K = %d, P = %d) exceeds the register-resident tile (%d x %d)", K, P,
              CSC_TILE_COLS, CSC_TILE_ROWS);
+    if (n_slabs(L) > MAX_SLABS) FAIL(-8, "atom length %d exceeds %d", L, MAX_SLABS * SLAB);
     if (max_sparsity > P * K) FAIL(-2, "max_sparsity exceeds the number of activations");
-    if (S == 0) return 0;
     const size_t need = csc_mmpdf_workspace_bytes(S, N, max_sparsity, connections, branches);
     if (max_sparsity > 1 && (workspace_bytes < need || !d_workspace))
         FAIL(-10, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
-    const int Lp = ceil8(L);
+    const int Lp = n_slabs(L) * SLAB;                      // residual window zero-padded to whole slabs
     const int W = csc_sim_words(N, L);
     const size_t lds = level_lds_bytes(N, Lp);
     if (lds > 80 * 1024) FAIL(-8, "signal too long for the LDS-resident node kernel (%zu B)", lds);
-    if ((size_t)K * W * 4 > 2 * SLAB * CSC_TILE_COLS * 4) FAIL(-8, "similarity row does not fit the slab buffer");
+    if ((size_t)K * (W + 1) * 4 > 2 * SLABF * 4) FAIL(-8, "similarity row does not fit the slab buffer");
     clear_stale_error();
     hipFuncSetAttribute((const void*)mmp_level_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 
@@ -814,9 +984,10 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
     hipStream_t st = (hipStream_t)stream;
     for (int d = 0; d < max_sparsity; ++d) {
         LevelArgs a;
-        a.bank32t = d_bank32t; a.bank64 = d_bank64; a.sim_bits = d_sim_bits;
+        a.bank32t = d_bank32t; a.meta = bank_meta(d_bank32t, K, L); a.bank64 = d_bank64; a.sim_bits = d_sim_bits;
         a.K = K; a.L = L; a.Lp = Lp; a.N = N; a.P = P; a.W = W;
         a.depth = d; a.Kmax = max_sparsity; a.connections = connections; a.NN = NN;
+        a.NS = N + TRI(max_sparsity); a.stagger_ticks = stagger_ticks();
         a.resid_in = (d == 0) ? d_signals : ws[d & 1];
         a.resid_out = (d + 1 < max_sparsity) ? ws[(d + 1) & 1] : nullptr;
         a.node_pos = d_node_pos; a.node_atom = d_node_atom; a.node_mse = d_node_mse; a.node_coef = d_node_coef;
@@ -848,7 +1019,7 @@ int csc_project_batch(const double* d_bank64, int K, int L, const double* d_sign
     if (P <= 0) FAIL(-6, "signal length %d shorter than atom length %d", N, L);
     if (kmax < 1 || kmax > KMAX) FAIL(-2, "support size %d outside [1, %d]", kmax, KMAX);
     if (M == 0) return 0;
-    const size_t lds = (size_t)((N + 1) & ~1) * 8 + sizeof(SmallLds);
+    const size_t lds = (size_t)((N + 1) & ~1) * 8 + sizeof(ProjLds);
     if (lds > 64 * 1024) FAIL(-8, "signal too long for the LDS-resident projection (%zu B)", lds);
     clear_stale_error();
     hipLaunchKernelGGL(project_kernel, dim3((unsigned)M), dim3(WG), lds, (hipStream_t)stream, d_bank64, K, L, P,

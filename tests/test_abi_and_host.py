@@ -50,11 +50,13 @@ def test_tree_shape_closed_form():
 def test_sizes_helpers():
     from csc_amd import _lib
     lib = _lib.lib()
-    assert lib.csc_bank32_elems(143, 492) == 512 * 144
-    assert lib.csc_bank32_elems(145, 492) == 2 * 512 * 144
+    # per 144-atom tile: 16 slabs x 9 column blocks x (32 x 16) floats + 208 ints of metadata
+    assert lib.csc_bank32_elems(143, 492) == 512 * 144 + 208
+    assert lib.csc_bank32_elems(145, 492) == 2 * (512 * 144 + 208)
     assert lib.csc_sim_words(738, 492) == 2 * ((2 * 247 - 1 + 63) // 64)
     assert lib.csc_sim_words(100, 492) == 0
-    assert lib.csc_mmpdf_workspace_bytes(10, 738, 5, 3, 3) == 2 * 10 * 3 * 738 * 8
+    # per frontier node: N residual samples + the packed Cholesky factor (15 doubles at depth 5)
+    assert lib.csc_mmpdf_workspace_bytes(10, 738, 5, 3, 3) == 2 * 10 * 3 * (738 + 15) * 8
 
 
 def test_candidate_paths_match_reference_table():

@@ -22,12 +22,27 @@ def bank(golden_bank):
 
 
 def test_bank_pack(bank, golden_bank):
+    """packed bank = column tiles sorted by support, blocked [slab][column tile][32 rows][16 atoms],
+    followed by the permutation and the per-slab non-zero block masks"""
     b = golden_bank["bank"]
     K, L = b.shape
-    img = bank.bank32t.cpu().numpy().reshape(-1, 512, 144)
-    assert img.shape[0] == 1
-    assert np.array_equal(img[0, :L, :K], b.T.astype(np.float32))
-    assert not img[0, L:].any() and not img[0, :, K:].any()
+    raw = bank.bank32t.cpu().numpy()
+    nslab = 16
+    tiles = raw[:nslab * 9 * 512].reshape(nslab, 9, 32, 16)
+    meta = raw[nslab * 9 * 512:].view(np.int32)
+    perm, masks = meta[:144], meta[144:144 + nslab]
+    assert sorted(perm.tolist()) == [-1] + list(range(K)) and perm[0] == -1
+    first = (b != 0).argmax(axis=1)
+    assert (np.diff(first[perm[1:]]) <= 0).all()                       # narrowest support first
+    img = tiles.transpose(0, 2, 1, 3).reshape(nslab * 32, 144)          # [row][column]
+    assert np.array_equal(img[:L, 1:], b.T.astype(np.float32)[:, perm[1:]])
+    assert not img[L:].any() and not img[:, 0].any()
+    for s in range(nslab):
+        want = sum(1 << ni for ni in range(9) if tiles[s, ni].any())
+        assert masks[s] == want
+    # the zero padding that is skipped: ~30 % of the (slab, column tile) blocks
+    active = sum(9 - (int(m) & -int(m)).bit_length() + 1 for m in masks if m)
+    assert active < 0.75 * nslab * 9
 
 
 def test_correlate_matches_reference(bank, golden_signals):
