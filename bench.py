@@ -189,6 +189,13 @@ def main():
         per_level = {str(d): float(np.mean([ms for lv, ms in spans if lv == d])) for d in range(MAX_SPARSITY)}
         flops_per_launch = S * flops_per_signal / MAX_SPARSITY       # 5 level launches share n_sel nodes
         achieved = flops_per_launch / (launch_ms * 1e-3) / 1e12
+        # MFMA flops actually issued: (32-row x 16-atom) blocks holding only the atoms' zero padding are
+        # skipped, every other block costs 4 waves x 32 v_mfma_f32_16x16x4_f32 (2048 flop each) per node
+        meta = bank.bank32t[-208:].view(torch.int32).cpu().numpy()
+        nslab = (L + 31) // 32
+        blocks = sum(9 - (int(m) & -int(m)).bit_length() + 1 for m in meta[144:144 + nslab] if m)
+        issued_per_node = blocks * 4 * 32 * 2048.0
+        issued = S * n_sel * issued_per_node / MAX_SPARSITY / (launch_ms * 1e-3) / 1e12
         traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):
@@ -210,7 +217,12 @@ def main():
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "mmp_level_kernel", "launch_ms_avg": launch_ms, "launch_ms_by_level": per_level,
                          "flops_per_launch": flops_per_launch, "flops_per_signal": flops_per_signal,
-                         "launches_timed": len(spans)},
+                         "launches_timed": len(spans),
+                         "mfma_issued": {"tflops": issued, "frac_of_peak": issued / FP32_MFMA_PEAK_TFLOPS,
+                                         "blocks_per_node": blocks, "of_dense_blocks": nslab * 9,
+                                         "note": "`achieved` counts the reference's dense 2*P*K*L flops per "
+                                                 "node; the kernel skips bank blocks that are all zero padding, "
+                                                 "so the matrix cores issue fewer flops than that"}},
             "cpu_baseline": cpu,
             "pcie_inclusive": {"value": S / pcie_s, "unit": "signals/s",
                                "note": "one call: host f64 signals -> HBM, solve, sparVar records -> host",

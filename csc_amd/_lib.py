@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcsc_hip.so")
+LIB_PATH = os.environ.get("CSC_HIP_LIB") or os.path.join(_HERE, "csrc", "libcsc_hip.so")   # env: dev builds only
 
 TILE_COLS = 144
 TILE_ROWS = 256

@@ -45,6 +45,17 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Development aid (make prof): per-phase shader-clock totals of mmp_level_kernel, summed over workgroups.
+#ifdef CSC_PHASE_PROF
+__device__ unsigned long long g_prof[16];
+#define PROF_INIT unsigned long long prof_t = __builtin_readcyclecounter()
+#define PROF_MARK(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) { unsigned long long n_ = __builtin_readcyclecounter(); \
+    atomicAdd(&g_prof[i], n_ - prof_t); prof_t = n_; } } while (0)
+#else
+#define PROF_INIT
+#define PROF_MARK(i)
+#endif
+
 static thread_local char g_err[256] = "";
 #define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
 
@@ -71,14 +82,32 @@ struct LevelArgs {
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// Wave reductions on the DPP network (no LDS traffic, ~2 VALU per step).  After the last step the
+// result is in lane 63 (wave) or in lanes 31 and 63 (the two 32-lane halves); the other lanes hold
+// partial values.
+#define DPP_QUAD_1032 0xB1
+#define DPP_QUAD_2301 0x4E
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double x) {       // lanes outside ROWMASK receive 0.0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWMASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWMASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double half_wave_sum(double v) {  // totals in lanes 31 and 63
+    v += dpp_f64<DPP_QUAD_1032, 0xF>(v);
+    v += dpp_f64<DPP_QUAD_2301, 0xF>(v);
+    v += dpp_f64<DPP_ROW_HALF_MIRROR, 0xF>(v);
+    v += dpp_f64<DPP_ROW_MIRROR, 0xF>(v);
+    v += dpp_f64<DPP_ROW_BCAST15, 0xA>(v);
     return v;
 }
-__device__ __forceinline__ double half_wave_sum(double v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+__device__ __forceinline__ double wave_sum(double v) {       // total in lane 63
+    v = half_wave_sum(v);
+    v += dpp_f64<DPP_ROW_BCAST31, 0xC>(v);
     return v;
 }
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
@@ -95,6 +124,40 @@ __device__ __forceinline__ int wave_min(int v) {
     return v;
 }
 __device__ __forceinline__ bool is_supp(float x) { return __float_as_uint(x) == SUPP_BITS; }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_max(float x) {          // lanes outside ROWMASK keep x
+    const int y = __builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, ROWMASK, 0xF, false);
+    return fmaxf(x, __int_as_float(y));
+}
+__device__ __forceinline__ float wave_max(float v) {         // maximum in lane 63
+    v = dpp_max<DPP_QUAD_1032, 0xF>(v);
+    v = dpp_max<DPP_QUAD_2301, 0xF>(v);
+    v = dpp_max<DPP_ROW_HALF_MIRROR, 0xF>(v);
+    v = dpp_max<DPP_ROW_MIRROR, 0xF>(v);
+    v = dpp_max<DPP_ROW_BCAST15, 0xA>(v);
+    v = dpp_max<DPP_ROW_BCAST31, 0xC>(v);
+    return v;
+}
+
+// sum_{i in [lo, hi)} a[i] * b[i] over LANES cooperating lanes (lane = index within the group); the
+// 8 load pairs of a chunk are issued together so the L2 round trips overlap.  B is global or LDS.
+template <int LANES, typename PB>
+__device__ __forceinline__ double dot_range(const double* __restrict__ a, PB b, int lo, int hi, int lane) {
+    double acc = 0.0;
+    for (int base = lo; base < hi; base += LANES * 8) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + lane + LANES * u;
+            const bool ok = i < hi;
+            av[u] = ok ? a[i] : 0.0;
+            bv[u] = ok ? b[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fma(av[u], bv[u], acc);
+    }
+    return acc;
+}
 
 // ------------------------------------------------------------------------------------------------
 // (256 x 144) x Lp correlation tile on v_mfma_f32_16x16x4_f32
@@ -256,7 +319,7 @@ __global__ __launch_bounds__(WG) void sim_table_kernel(const double* __restrict_
         ss += v * v;
     }
     ss = wave_sum(ss);
-    if ((tid & 63) == 0) wpart[tid >> 6] = ss;
+    if ((tid & 63) == 63) wpart[tid >> 6] = ss;
     __syncthreads();
     const double nrm = sqrt(wpart[0] + wpart[1] + wpart[2] + wpart[3]);
     uint32_t* row = bits + ((size_t)ksel * K + k) * W;
@@ -352,7 +415,7 @@ __device__ __forceinline__ void support_ls(ProjLds* sl, int n, const double* r64
             const int p = sl->sup_pos[q];
             for (int i = lane; i < L; i += 64) v = fma(at[i], r64[p + i], v);
             v = wave_sum(v);
-            if (lane == 0) sl->b[q] = v;
+            if (lane == 63) sl->b[q] = v;
         } else {
             int r = q - n, i1 = 0;
             while (r > i1) { r -= i1 + 1; ++i1; }               // (i1, i2 = r), i2 <= i1
@@ -363,7 +426,7 @@ __device__ __forceinline__ void support_ls(ProjLds* sl, int n, const double* r64
             const int lo = max(0, -dp), hi = min(L, L - dp);
             for (int i = lo + lane; i < hi; i += 64) v = fma(a1[i], a2[i + dp], v);
             v = wave_sum(v);
-            if (lane == 0) { sl->G[i1][i2] = v; sl->G[i2][i1] = v; }
+            if (lane == 63) { sl->G[i1][i2] = v; sl->G[i2][i1] = v; }
         }
     }
     __syncthreads();
@@ -447,7 +510,7 @@ __global__ __launch_bounds__(WG) void project_kernel(const double* __restrict__ 
         cs = fma(v, v, cs);
     }
     cs = wave_sum(cs);
-    if (lane == 0) sl->wsum[wave] = cs;
+    if (lane == 63) sl->wsum[wave] = cs;
     __syncthreads();
     if (tid == 0 && mse) mse[m] = (sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3]) / (double)N;
     if (coef && tid < kmax) coef[m * kmax + tid] = tid < n ? sl->x[tid] : 0.0;
@@ -467,6 +530,7 @@ struct NodeLds {
     int cand_idx[CAND_CAP];
     int sup_pos[KMAX + 1], sup_atom[KMAX + 1];
     uint32_t masks[MAX_SLABS];
+    int perm[CSC_TILE_COLS];       // atom of each bank column (-1 = padding)
     float wmax[WG / 64];
     int widx[WG / 64], wsupp[WG / 64];
     int cand_cnt, chosen, i32, bad, odd_slot;
@@ -509,15 +573,25 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
         }
     }
 
+    PROF_INIT;
     // ---- residual -> LDS, norm; ancestors, parent's factor, bank metadata -----------------------------
     const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
     double ss = 0.0;
-    for (int i = tid; i < Npad; i += WG) {
-        const double v = (i < N) ? rin[i] : 0.0;
-        r64[i] = v;
-        ss = fma(v, v, ss);
+    for (int i0 = 0; i0 < R32; i0 += 4 * WG) {                        // R32 > Npad: one sweep fills both copies
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + tid + WG * u;
+            v[u] = (i < N) ? rin[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + tid + WG * u;
+            if (i < Npad) r64[i] = v[u];
+            if (i < R32) r32[i] = (float)v[u];
+            ss = fma(v[u], v[u], ss);
+        }
     }
-    for (int i = tid; i < R32; i += WG) r32[i] = (i < N) ? (float)rin[i] : 0.f;
     if (tid < d) {
         const int e = tid + 1;                                        // level of this ancestor
         const size_t id = s * a.NN + a.ts.off[e] + (j % a.ts.pw[e]);
@@ -527,105 +601,140 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     }
     if (tid >= 64 && tid < 64 + TRI(d)) sl->Lf[tid - 64] = rin[N + tid - 64];
     if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
+    if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
     ss = wave_sum(ss);
-    if (lane == 0) sl->wsum[wave] = ss;
+    if (lane == 63) sl->wsum[wave] = ss;
     __syncthreads();
     const double rnorm2 = sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3];
     const float delta = DELTA_REL * (float)sqrt(rnorm2);
 
+    PROF_MARK(0);
     // ---- correlations on the matrix cores ------------------------------------------------------------
     f32x4 acc[MT][NT];
     corr_tile_gemm(a.bank32t, sl->masks, (L + SLAB - 1) / SLAB, r32 + 64 * wave + lr + lq, slab, acc);
 
+    PROF_MARK(1);
     int permv[NT];                                // atom of this lane's column in tile ni (-1 = padding)
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) permv[ni] = a.meta[16 * ni + lr];
+    for (int ni = 0; ni < NT; ++ni) permv[ni] = sl->perm[16 * ni + lr];
     const int prow = 64 * wave + 4 * lq;          // + 16*mi + reg
     const int rowK = prow * K;
+    // entries outside the (P x K) matrix never win: rows >= P (last row tile only) and padding columns
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
+        if (64 * wave + 16 * mi + 15 >= P) {                         // wave-uniform
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni)
+            for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
-                if (prow + 16 * mi + rg >= P || permv[ni] < 0) acc[mi][ni][rg] = -INFINITY;
+                for (int rg = 0; rg < 4; ++rg)
+                    if (prow + 16 * mi + rg >= P) acc[mi][ni][rg] = -INFINITY;
+        }
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+        if (__ballot(permv[ni] < 0)) {                               // wave-uniform
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    if (permv[ni] < 0) acc[mi][ni][rg] = -INFINITY;
+        }
 
     // ---- children, one selection round per sibling -------------------------------------------------
+    bool lane_supp = false;                       // this lane holds a suppressed (value 0) entry
     for (int t = 0; t < nch; ++t) {
-        // (a) fp32 maximum (lowest flattened index pos*K + atom on ties)
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
-        int Ka = K;                                // opaque copy: keeps the 144 flattened indices from being
-        asm volatile("" : "+v"(Ka));               // hoisted out of the sibling loop into registers
+        // (a) fp32 maximum.  Suppressed entries carry a quiet NaN, which fmaxf (maxNum) skips; their
+        //     value 0 enters through lane_supp.
+        float lmax = -INFINITY;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int rbase = rowK + (16 * mi + rg) * Ka;
+            for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-                for (int ni = 0; ni < NT; ++ni) {
-                    const float x = acc[mi][ni][rg];
-                    const float e = is_supp(x) ? 0.f : x;
-                    const int idx = rbase + permv[ni];
-                    if (e > bv || (e == bv && idx < bi)) { bv = e; bi = idx; }
-                }
-            }
-        wave_argmax(bv, bi);
-        if (lane == 0) { sl->wmax[wave] = bv; sl->widx[wave] = bi; }
+                for (int rg = 0; rg < 4; ++rg) lmax = fmaxf(lmax, acc[mi][ni][rg]);
+        float bv = wave_max(lane_supp ? fmaxf(lmax, 0.f) : lmax);
+        if (lane == 63) sl->wmax[wave] = bv;
+        if (tid == 0) sl->cand_cnt = 0;
         __syncthreads();
-        if (tid == 0) {
-            float m = sl->wmax[0]; int mi_ = sl->widx[0];
-            for (int w = 1; w < WG / 64; ++w) {
-                const float v = sl->wmax[w]; const int i = sl->widx[w];
-                if (v > m || (v == m && i < mi_)) { m = v; mi_ = i; }
-            }
-            sl->m32 = m; sl->i32 = mi_; sl->cand_cnt = 0;
-        }
-        __syncthreads();
-        const float tau = sl->m32 - delta;
+        const float m32 = fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
+        const float tau = m32 - delta;
         const bool zero_band = (0.f >= tau);
         // (b) every unsuppressed entry inside the fp32 error band of the maximum is a candidate
-        int first_supp = 0x7fffffff;
-        int Kb = K;
+        //     (NaN >= tau is false).  Only the few lanes whose own maximum reaches the band look at
+        //     their 144 entries: a dense, branch-free bit mask first (straight-line code with a branch
+        //     per entry made the instruction fetch, not the ALU, the cost of this phase), then a short
+        //     loop over the set bits.  Entry e = (4*mi + rg) * 9 + ni.
+        int Kb = K;                                // opaque copy: keeps index arithmetic out of the hot path
         asm volatile("" : "+v"(Kb));
+        if (lmax >= tau) {
+            uint32_t mk[5] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
+            for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int rbase = rowK + (16 * mi + rg) * Kb;
+                for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-                for (int ni = 0; ni < NT; ++ni) {
-                    const float x = acc[mi][ni][rg];
-                    if (is_supp(x)) {
-                        if (zero_band) first_supp = min(first_supp, rbase + permv[ni]);
-                    } else if (x >= tau) {
-                        const int slot = atomicAdd(&sl->cand_cnt, 1);
-                        if (slot < CAND_CAP) sl->cand_idx[slot] = rbase + permv[ni];
+                    for (int ni = 0; ni < NT; ++ni) {
+                        const int e = (4 * mi + rg) * NT + ni;
+                        mk[e >> 5] |= (acc[mi][ni][rg] >= tau) ? (1u << (e & 31)) : 0u;
                     }
+#pragma unroll
+            for (int w = 0; w < 5; ++w) {
+                uint32_t mm = mk[w];
+                while (mm) {
+                    const int e = 32 * w + __builtin_ctz(mm);
+                    mm &= mm - 1;
+                    const int r = e / NT, ni = e - r * NT;
+                    const int slot = atomicAdd(&sl->cand_cnt, 1);
+                    if (slot < CAND_CAP)
+                        sl->cand_idx[slot] = rowK + (16 * (r >> 2) + (r & 3)) * Kb + sl->perm[16 * ni + lr];
                 }
             }
-        if (zero_band) {
+        }
+        if (zero_band) {                           // degenerate: the value 0 of the suppressed entries competes
+            int first_supp = 0x7fffffff;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni)
+                        if (is_supp(acc[mi][ni][rg]))
+                            first_supp = min(first_supp, rowK + (16 * mi + rg) * Kb + permv[ni]);
             first_supp = wave_min(first_supp);
             if (lane == 0) sl->wsupp[wave] = first_supp;
         }
         __syncthreads();
+        PROF_MARK(2);
         const int ncand_raw = sl->cand_cnt;
         const int ncand = min(ncand_raw, CAND_CAP);
+        if (ncand_raw > CAND_CAP) {
+            // overflow (never seen on real data): fall back to the fp32 arg-max, lowest index
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni) {
+                        const float x = acc[mi][ni][rg];
+                        const float e = is_supp(x) ? 0.f : x;
+                        if (e == m32) bi = min(bi, rowK + (16 * mi + rg) * Kb + permv[ni]);
+                    }
+            bi = wave_min(bi);
+            if (lane == 0) sl->widx[wave] = bi;
+        }
         // (c) fp64 re-score: one wave per candidate
         for (int c = wave; c < ncand; c += WG / 64) {
             const int idx = sl->cand_idx[c];
             const int p = idx / K, k = idx - p * K;
-            const double* at = a.bank64 + (size_t)k * L;
-            double v = 0.0;
-            for (int i = lane; i < L; i += 64) v = fma(at[i], r64[p + i], v);
+            double v = dot_range<64>(a.bank64 + (size_t)k * L, r64 + p, 0, L, lane);
             v = wave_sum(v);
-            if (lane == 0) sl->cand_val[c] = v;
+            if (lane == 63) sl->cand_val[c] = v;
         }
         __syncthreads();
         if (tid == 0) {
             int chosen;
             if (ncand_raw > CAND_CAP) {
-                chosen = sl->i32;
+                chosen = min(min(sl->widx[0], sl->widx[1]), min(sl->widx[2], sl->widx[3]));
                 if (a.stats) atomicAdd(&a.stats[0], 1);
             } else {
                 double bestv = sl->cand_val[0]; int besti = sl->cand_idx[0];
@@ -640,11 +749,13 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
                 }
                 chosen = besti;
             }
+            if (a.stats) atomicAdd(&a.stats[2], ncand);
             sl->chosen = chosen;
             sl->sup_pos[d] = chosen / K;
             sl->sup_atom[d] = chosen - (chosen / K) * K;
         }
         __syncthreads();
+        PROF_MARK(3);
         const int p_sel = sl->sup_pos[d], k_sel = sl->sup_atom[d];
         const int jc = j + t * stride;                               // child's index in level d+1
         const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
@@ -654,22 +765,22 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
             const int hw = tid >> 5, hl = tid & 31;
             const double* an = a.bank64 + (size_t)k_sel * L;
             for (int q = hw; q < d + 2; q += WG / 32) {
-                double v = 0.0;
+                double v;
                 if (q < d) {                                         // <a_new @ p_sel, a_q @ p_q>
                     const double* aq = a.bank64 + (size_t)sl->sup_atom[q] * L;
                     const int dp = p_sel - sl->sup_pos[q];           // a_q index = i + dp
-                    const int lo = max(0, -dp), hi = min(L, L - dp);
-                    for (int i = lo + hl; i < hi; i += 32) v = fma(an[i], aq[i + dp], v);
+                    v = dot_range<32>(an, aq + dp, max(0, -dp), min(L, L - dp), hl);
                 } else if (q == d) {                                 // ||a_new||^2
-                    for (int i = hl; i < L; i += 32) v = fma(an[i], an[i], v);
+                    v = dot_range<32>(an, an, 0, L, hl);
                 } else {                                             // <a_new, r_parent>
-                    for (int i = hl; i < L; i += 32) v = fma(an[i], r64[p_sel + i], v);
+                    v = dot_range<32>(an, r64 + p_sel, 0, L, hl);
                 }
                 v = half_wave_sum(v);
-                if (hl == 0) sl->g[q] = v;
+                if (hl == 31) sl->g[q] = v;
             }
         }
         __syncthreads();
+        PROF_MARK(4);
         if (tid == 0) {
             // factor row: Lf y = g, l_dd^2 = g_dd - y.y.  A dead column (an activation selected twice,
             // src/csc/mmp.py:56 sets the same mask bit again) has diagonal 0 and is skipped everywhere.
@@ -704,21 +815,43 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
             if (bad && a.stats) atomicAdd(&a.stats[1], 1);
         }
         __syncthreads();
+        PROF_MARK(5);
         // ---- child residual, factor, MSE ------------------------------------------------------------
         double* rout = a.resid_out ? a.resid_out + (s * Fc + jc) * (size_t)a.NS : nullptr;
         double cs = 0.0;
-        for (int n = tid; n < N; n += WG) {
-            double v = r64[n];
-            for (int i = 0; i <= d; ++i) {
-                const int o = n - sl->sup_pos[i];
-                if (o >= 0 && o < L) v = fma(-sl->x[i], a.bank64[(size_t)sl->sup_atom[i] * L + o], v);
+        for (int n0 = 0; n0 < N; n0 += 3 * WG) {
+            double v[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int n = n0 + tid + WG * u;
+                v[u] = n < N ? r64[n] : 0.0;
             }
-            if (rout) rout[n] = v;
-            cs = fma(v, v, cs);
+#pragma unroll 2
+            for (int i = 0; i <= d; ++i) {
+                const double* ai = a.bank64 + (size_t)sl->sup_atom[i] * L;
+                const int pi = sl->sup_pos[i];
+                const double xi = sl->x[i];
+                double av[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int o = n0 + tid + WG * u - pi;
+                    av[u] = ((unsigned)o < (unsigned)L) ? ai[o] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) v[u] = fma(-xi, av[u], v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int n = n0 + tid + WG * u;
+                if (n < N) {
+                    if (rout) rout[n] = v[u];
+                    cs = fma(v[u], v[u], cs);
+                }
+            }
         }
         if (rout && tid < TRI(d + 1)) rout[N + tid] = tid < TRI(d) ? sl->Lf[tid] : sl->y[tid - TRI(d)];
         cs = wave_sum(cs);
-        if (lane == 0) sl->wsum[wave] = cs;
+        if (lane == 63) sl->wsum[wave] = cs;
         __syncthreads();
         if (tid == 0) {
             a.node_pos[cid] = p_sel;
@@ -729,27 +862,30 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
             a.node_coef[cid * a.Kmax + tid] =
                 tid <= d ? sl->x[tid] + (tid < d ? sl->coefpar[tid] : 0.0) : 0.0;
 
+        PROF_MARK(6);
         // ---- suppress the chosen atom's similarity disk for the next sibling ----------------------
         if (t + 1 < nch) {
             const int W = a.W, W1 = a.W + 1;                         // LDS rows padded by one word
             const uint32_t* g = a.sim_bits + (size_t)k_sel * K * W;
             for (int i = tid; i < K * W; i += WG) simrow[(i / W) * W1 + (i % W)] = g[i];
             __syncthreads();
+            const int dp0 = prow - p_sel + P - 1;                    // + 16*mi + rg: bit index of this entry
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
+            for (int ni = 0; ni < NT; ++ni) {
+                const uint32_t* row = simrow + max(permv[ni], 0) * W1;
 #pragma unroll
-                for (int ni = 0; ni < NT; ++ni)
+                for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
-                        const int p = prow + 16 * mi + rg, k = permv[ni];
-                        if (p < P && k >= 0) {
-                            const int dpi = p - p_sel + P - 1;
-                            if ((simrow[k * W1 + (dpi >> 5)] >> (dpi & 31)) & 1u)
-                                acc[mi][ni][rg] = __uint_as_float(SUPP_BITS);
-                        }
+                        const int dpi = dp0 + 16 * mi + rg;
+                        const bool hit = ((row[dpi >> 5] >> (dpi & 31)) & 1u) && acc[mi][ni][rg] > -INFINITY;
+                        acc[mi][ni][rg] = hit ? __uint_as_float(SUPP_BITS) : acc[mi][ni][rg];
+                        lane_supp |= hit;
                     }
+            }
         }
         __syncthreads();
+        PROF_MARK(7);
     }
 }
 
@@ -974,8 +1110,11 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
         FAIL(-10, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
     const int Lp = n_slabs(L) * SLAB;                      // residual window zero-padded to whole slabs
     const int W = csc_sim_words(N, L);
-    const size_t lds = level_lds_bytes(N, Lp);
-    if (lds > 80 * 1024) FAIL(-8, "signal too long for the LDS-resident node kernel (%zu B)", lds);
+    size_t lds = level_lds_bytes(N, Lp);
+#ifdef CSC_PHASE_PROF
+    if (getenv("CSC_EXTRA_LDS")) lds += (size_t)atoi(getenv("CSC_EXTRA_LDS"));   // force 1 workgroup per CU
+#endif
+    if (lds > 150 * 1024) FAIL(-8, "signal too long for the LDS-resident node kernel (%zu B)", lds);
     if ((size_t)K * (W + 1) * 4 > 2 * SLABF * 4) FAIL(-8, "similarity row does not fit the slab buffer");
     clear_stale_error();
     hipFuncSetAttribute((const void*)mmp_level_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1065,5 +1204,14 @@ int csc_timer_read(csc_timer* t, float* ms, int* tag, int n) {
     }
     return m;
 }
+
+#ifdef CSC_PHASE_PROF
+int csc_prof_read(unsigned long long* out16, int reset) {
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z); }
+    return 0;
+}
+#endif
 
 }  // extern "C"
