@@ -51,9 +51,11 @@ __device__ unsigned long long g_prof[16];
 #define PROF_INIT unsigned long long prof_t = __builtin_readcyclecounter()
 #define PROF_MARK(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) { unsigned long long n_ = __builtin_readcyclecounter(); \
     atomicAdd(&g_prof[i], n_ - prof_t); prof_t = n_; } } while (0)
+#define PROF_MARK_EXT(i)          /* marks inside shared device functions are not timed separately */
 #else
 #define PROF_INIT
 #define PROF_MARK(i)
+#define PROF_MARK_EXT(i)
 #endif
 
 static thread_local char g_err[256] = "";
@@ -537,6 +539,199 @@ struct NodeLds {
     float m32;
 };
 
+// ---- pieces of a node's work shared by the register-resident and the tiled level kernels ------------
+
+// residual -> LDS (fp64 + fp32 window copy), ancestors' (pos, atom), parent's coefficients and Cholesky
+// factor.  Returns the fp32 candidate band delta = 2^-14 * ||residual||.  Ends with a barrier.
+__device__ __forceinline__ float node_prologue(const LevelArgs& a, NodeLds* sl, double* r64, float* r32,
+                                               int Npad, int R32, const double* __restrict__ rin, size_t s, int j) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = a.N, d = a.depth;
+    double ss = 0.0;
+    for (int i0 = 0; i0 < R32; i0 += 4 * WG) {                        // R32 > Npad: one sweep fills both copies
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + tid + WG * u;
+            v[u] = (i < N) ? rin[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + tid + WG * u;
+            if (i < Npad) r64[i] = v[u];
+            if (i < R32) r32[i] = (float)v[u];
+            ss = fma(v[u], v[u], ss);
+        }
+    }
+    if (tid < d) {
+        const int e = tid + 1;                                        // level of this ancestor
+        const size_t id = s * a.NN + a.ts.off[e] + (j % a.ts.pw[e]);
+        sl->sup_pos[tid] = a.node_pos[id];
+        sl->sup_atom[tid] = a.node_atom[id];
+        sl->coefpar[tid] = a.node_coef ? a.node_coef[(s * a.NN + a.ts.off[d] + j) * (size_t)a.Kmax + tid] : 0.0;
+    }
+    if (tid >= 64 && tid < 64 + TRI(d)) sl->Lf[tid - 64] = rin[N + tid - 64];
+    ss = wave_sum(ss);
+    if (lane == 63) sl->wsum[wave] = ss;
+    __syncthreads();
+    const double rnorm2 = sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3];
+    return DELTA_REL * (float)sqrt(rnorm2);
+}
+
+// (c) fp64 re-score of the candidates in sl->cand_idx (one wave per candidate), (d) the choice: fp64
+// maximum, lowest flattened index on ties; with zero_band the first suppressed index (sl->wsupp) competes
+// with value 0; on candidate overflow the fp32 arg-max (sl->widx) is taken.  Writes sl->sup_pos/atom[d].
+__device__ __forceinline__ void rescore_and_choose(const LevelArgs& a, NodeLds* sl, const double* r64,
+                                                   int ncand_raw, bool zero_band) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, L = a.L, d = a.depth;
+    const int ncand = min(ncand_raw, CAND_CAP);
+    for (int c = wave; c < ncand; c += WG / 64) {
+        const int idx = sl->cand_idx[c];
+        const int p = idx / K, k = idx - p * K;
+        double v = dot_range<64>(a.bank64 + (size_t)k * L, r64 + p, 0, L, lane);
+        v = wave_sum(v);
+        if (lane == 63) sl->cand_val[c] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int chosen;
+        if (ncand_raw > CAND_CAP) {
+            chosen = min(min(sl->widx[0], sl->widx[1]), min(sl->widx[2], sl->widx[3]));
+            if (a.stats) atomicAdd(&a.stats[0], 1);
+        } else {
+            double bestv = ncand ? sl->cand_val[0] : -INFINITY; int besti = ncand ? sl->cand_idx[0] : 0x7fffffff;
+            for (int c = 1; c < ncand; ++c) {
+                const double v = sl->cand_val[c]; const int i = sl->cand_idx[c];
+                if (v > bestv || (v == bestv && i < besti)) { bestv = v; besti = i; }
+            }
+            if (zero_band) {
+                int z = 0x7fffffff;
+                for (int w = 0; w < WG / 64; ++w) z = min(z, sl->wsupp[w]);
+                if (z != 0x7fffffff && (0.0 > bestv || (0.0 == bestv && z < besti))) besti = z;
+            }
+            chosen = besti;
+        }
+        if (a.stats) atomicAdd(&a.stats[2], ncand);
+        sl->chosen = chosen;
+        sl->sup_pos[d] = chosen / K;
+        sl->sup_atom[d] = chosen - (chosen / K) * K;
+    }
+    __syncthreads();
+}
+
+// Child jc of the node: least squares of the parent residual on the child's support by extending the
+// parent's Cholesky factor with one row, child residual + factor -> workspace, MSE, coefficients,
+// (pos, atom) -> node tables.
+__device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLds* sl, const double* r64,
+                                                      size_t s, int jc, size_t cid) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = a.N, L = a.L, d = a.depth;
+    const int p_sel = sl->sup_pos[d], k_sel = sl->sup_atom[d];
+    const int Fc = a.ts.F[d + 1];
+    // ---- one new Gram column (fp64 dots, one per half-wave) ------------------------------------------
+    {
+        const int hw = tid >> 5, hl = tid & 31;
+        const double* an = a.bank64 + (size_t)k_sel * L;
+        for (int q = hw; q < d + 2; q += WG / 32) {
+            double v;
+            if (q < d) {                                         // <a_new @ p_sel, a_q @ p_q>
+                const double* aq = a.bank64 + (size_t)sl->sup_atom[q] * L;
+                const int dp = p_sel - sl->sup_pos[q];           // a_q index = i + dp
+                v = dot_range<32>(an, aq + dp, max(0, -dp), min(L, L - dp), hl);
+            } else if (q == d) {                                 // ||a_new||^2
+                v = dot_range<32>(an, an, 0, L, hl);
+            } else {                                             // <a_new, r_parent>
+                v = dot_range<32>(an, r64 + p_sel, 0, L, hl);
+            }
+            v = half_wave_sum(v);
+            if (hl == 31) sl->g[q] = v;
+        }
+    }
+    __syncthreads();
+    PROF_MARK_EXT(4);
+    if (tid == 0) {
+        // factor row: Lf y = g, l_dd^2 = g_dd - y.y.  A dead column (an activation selected twice,
+        // src/csc/mmp.py:56 sets the same mask bit again) has diagonal 0 and is skipped everywhere.
+        double yy = 0.0;
+        for (int i = 0; i < d; ++i) {
+            const double dg = sl->Lf[TRI(i) + i];
+            double v = sl->g[i];
+            for (int m = 0; m < i; ++m) v -= sl->Lf[TRI(i) + m] * sl->y[m];
+            v = (dg != 0.0) ? v / dg : 0.0;
+            sl->y[i] = v;
+            yy = fma(v, v, yy);
+        }
+        const double gdd = sl->g[d], sdd = gdd - yy;
+        const bool bad = !(sdd > 1e-13 * gdd);
+        double xd = 0.0;
+        if (bad) {
+            for (int i = 0; i < d; ++i) sl->y[i] = 0.0;
+            sl->y[d] = 0.0;
+        } else {
+            sl->y[d] = sqrt(sdd);
+            xd = sl->g[d + 1] / sdd;                             // (beta / l_dd) / l_dd
+        }
+        // Lf^T x = z with z = (0, ..., 0, beta / l_dd): the parent residual is orthogonal to the
+        // ancestors' atoms, so only the new right-hand side entry is non-zero
+        sl->x[d] = xd;
+        for (int r = d - 1; r >= 0; --r) {
+            const double dg = sl->Lf[TRI(r) + r];
+            double v = -sl->y[r] * xd;
+            for (int m = r + 1; m < d; ++m) v -= sl->Lf[TRI(m) + r] * sl->x[m];
+            sl->x[r] = (dg != 0.0) ? v / dg : 0.0;
+        }
+        if (bad && a.stats) atomicAdd(&a.stats[1], 1);
+    }
+    __syncthreads();
+    PROF_MARK_EXT(5);
+    // ---- child residual, factor, MSE ------------------------------------------------------------------
+    double* rout = a.resid_out ? a.resid_out + (s * Fc + jc) * (size_t)a.NS : nullptr;
+    double cs = 0.0;
+    for (int n0 = 0; n0 < N; n0 += 3 * WG) {
+        double v[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int n = n0 + tid + WG * u;
+            v[u] = n < N ? r64[n] : 0.0;
+        }
+#pragma unroll 2
+        for (int i = 0; i <= d; ++i) {
+            const double* ai = a.bank64 + (size_t)sl->sup_atom[i] * L;
+            const int pi = sl->sup_pos[i];
+            const double xi = sl->x[i];
+            double av[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int o = n0 + tid + WG * u - pi;
+                av[u] = ((unsigned)o < (unsigned)L) ? ai[o] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) v[u] = fma(-xi, av[u], v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int n = n0 + tid + WG * u;
+            if (n < N) {
+                if (rout) rout[n] = v[u];
+                cs = fma(v[u], v[u], cs);
+            }
+        }
+    }
+    if (rout && tid < TRI(d + 1)) rout[N + tid] = tid < TRI(d) ? sl->Lf[tid] : sl->y[tid - TRI(d)];
+    cs = wave_sum(cs);
+    if (lane == 63) sl->wsum[wave] = cs;
+    __syncthreads();
+    if (tid == 0) {
+        a.node_pos[cid] = p_sel;
+        a.node_atom[cid] = k_sel;
+        a.node_mse[cid] = (sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3]) / (double)N;
+    }
+    if (a.node_coef && tid < a.Kmax)
+        a.node_coef[cid * a.Kmax + tid] =
+            tid <= d ? sl->x[tid] + (tid < d ? sl->coefpar[tid] : 0.0) : 0.0;
+}
+
 __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     extern __shared__ double lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -574,39 +769,11 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     }
 
     PROF_INIT;
-    // ---- residual -> LDS, norm; ancestors, parent's factor, bank metadata -----------------------------
     const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
-    double ss = 0.0;
-    for (int i0 = 0; i0 < R32; i0 += 4 * WG) {                        // R32 > Npad: one sweep fills both copies
-        double v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + tid + WG * u;
-            v[u] = (i < N) ? rin[i] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + tid + WG * u;
-            if (i < Npad) r64[i] = v[u];
-            if (i < R32) r32[i] = (float)v[u];
-            ss = fma(v[u], v[u], ss);
-        }
-    }
-    if (tid < d) {
-        const int e = tid + 1;                                        // level of this ancestor
-        const size_t id = s * a.NN + a.ts.off[e] + (j % a.ts.pw[e]);
-        sl->sup_pos[tid] = a.node_pos[id];
-        sl->sup_atom[tid] = a.node_atom[id];
-        sl->coefpar[tid] = a.node_coef ? a.node_coef[(s * a.NN + a.ts.off[d] + j) * (size_t)a.Kmax + tid] : 0.0;
-    }
-    if (tid >= 64 && tid < 64 + TRI(d)) sl->Lf[tid - 64] = rin[N + tid - 64];
+    const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j);
     if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
     if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
-    ss = wave_sum(ss);
-    if (lane == 63) sl->wsum[wave] = ss;
     __syncthreads();
-    const double rnorm2 = sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3];
-    const float delta = DELTA_REL * (float)sqrt(rnorm2);
 
     PROF_MARK(0);
     // ---- correlations on the matrix cores ------------------------------------------------------------
@@ -705,7 +872,6 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
         __syncthreads();
         PROF_MARK(2);
         const int ncand_raw = sl->cand_cnt;
-        const int ncand = min(ncand_raw, CAND_CAP);
         if (ncand_raw > CAND_CAP) {
             // overflow (never seen on real data): fall back to the fp32 arg-max, lowest index
             int bi = 0x7fffffff;
@@ -722,145 +888,13 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
             bi = wave_min(bi);
             if (lane == 0) sl->widx[wave] = bi;
         }
-        // (c) fp64 re-score: one wave per candidate
-        for (int c = wave; c < ncand; c += WG / 64) {
-            const int idx = sl->cand_idx[c];
-            const int p = idx / K, k = idx - p * K;
-            double v = dot_range<64>(a.bank64 + (size_t)k * L, r64 + p, 0, L, lane);
-            v = wave_sum(v);
-            if (lane == 63) sl->cand_val[c] = v;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int chosen;
-            if (ncand_raw > CAND_CAP) {
-                chosen = min(min(sl->widx[0], sl->widx[1]), min(sl->widx[2], sl->widx[3]));
-                if (a.stats) atomicAdd(&a.stats[0], 1);
-            } else {
-                double bestv = sl->cand_val[0]; int besti = sl->cand_idx[0];
-                for (int c = 1; c < ncand; ++c) {
-                    const double v = sl->cand_val[c]; const int i = sl->cand_idx[c];
-                    if (v > bestv || (v == bestv && i < besti)) { bestv = v; besti = i; }
-                }
-                if (zero_band) {
-                    int z = 0x7fffffff;
-                    for (int w = 0; w < WG / 64; ++w) z = min(z, sl->wsupp[w]);
-                    if (z != 0x7fffffff && (0.0 > bestv || (0.0 == bestv && z < besti))) besti = z;
-                }
-                chosen = besti;
-            }
-            if (a.stats) atomicAdd(&a.stats[2], ncand);
-            sl->chosen = chosen;
-            sl->sup_pos[d] = chosen / K;
-            sl->sup_atom[d] = chosen - (chosen / K) * K;
-        }
-        __syncthreads();
+        rescore_and_choose(a, sl, r64, ncand_raw, zero_band);
         PROF_MARK(3);
         const int p_sel = sl->sup_pos[d], k_sel = sl->sup_atom[d];
         const int jc = j + t * stride;                               // child's index in level d+1
         const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
 
-        // ---- child least squares: one new Gram column (fp64 dots, one per half-wave) ---------------
-        {
-            const int hw = tid >> 5, hl = tid & 31;
-            const double* an = a.bank64 + (size_t)k_sel * L;
-            for (int q = hw; q < d + 2; q += WG / 32) {
-                double v;
-                if (q < d) {                                         // <a_new @ p_sel, a_q @ p_q>
-                    const double* aq = a.bank64 + (size_t)sl->sup_atom[q] * L;
-                    const int dp = p_sel - sl->sup_pos[q];           // a_q index = i + dp
-                    v = dot_range<32>(an, aq + dp, max(0, -dp), min(L, L - dp), hl);
-                } else if (q == d) {                                 // ||a_new||^2
-                    v = dot_range<32>(an, an, 0, L, hl);
-                } else {                                             // <a_new, r_parent>
-                    v = dot_range<32>(an, r64 + p_sel, 0, L, hl);
-                }
-                v = half_wave_sum(v);
-                if (hl == 31) sl->g[q] = v;
-            }
-        }
-        __syncthreads();
-        PROF_MARK(4);
-        if (tid == 0) {
-            // factor row: Lf y = g, l_dd^2 = g_dd - y.y.  A dead column (an activation selected twice,
-            // src/csc/mmp.py:56 sets the same mask bit again) has diagonal 0 and is skipped everywhere.
-            double yy = 0.0;
-            for (int i = 0; i < d; ++i) {
-                const double dg = sl->Lf[TRI(i) + i];
-                double v = sl->g[i];
-                for (int m = 0; m < i; ++m) v -= sl->Lf[TRI(i) + m] * sl->y[m];
-                v = (dg != 0.0) ? v / dg : 0.0;
-                sl->y[i] = v;
-                yy = fma(v, v, yy);
-            }
-            const double gdd = sl->g[d], sdd = gdd - yy;
-            const bool bad = !(sdd > 1e-13 * gdd);
-            double xd = 0.0;
-            if (bad) {
-                for (int i = 0; i < d; ++i) sl->y[i] = 0.0;
-                sl->y[d] = 0.0;
-            } else {
-                sl->y[d] = sqrt(sdd);
-                xd = sl->g[d + 1] / sdd;                             // (beta / l_dd) / l_dd
-            }
-            // Lf^T x = z with z = (0, ..., 0, beta / l_dd): the parent residual is orthogonal to the
-            // ancestors' atoms, so only the new right-hand side entry is non-zero
-            sl->x[d] = xd;
-            for (int r = d - 1; r >= 0; --r) {
-                const double dg = sl->Lf[TRI(r) + r];
-                double v = -sl->y[r] * xd;
-                for (int m = r + 1; m < d; ++m) v -= sl->Lf[TRI(m) + r] * sl->x[m];
-                sl->x[r] = (dg != 0.0) ? v / dg : 0.0;
-            }
-            if (bad && a.stats) atomicAdd(&a.stats[1], 1);
-        }
-        __syncthreads();
-        PROF_MARK(5);
-        // ---- child residual, factor, MSE ------------------------------------------------------------
-        double* rout = a.resid_out ? a.resid_out + (s * Fc + jc) * (size_t)a.NS : nullptr;
-        double cs = 0.0;
-        for (int n0 = 0; n0 < N; n0 += 3 * WG) {
-            double v[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int n = n0 + tid + WG * u;
-                v[u] = n < N ? r64[n] : 0.0;
-            }
-#pragma unroll 2
-            for (int i = 0; i <= d; ++i) {
-                const double* ai = a.bank64 + (size_t)sl->sup_atom[i] * L;
-                const int pi = sl->sup_pos[i];
-                const double xi = sl->x[i];
-                double av[3];
-#pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int o = n0 + tid + WG * u - pi;
-                    av[u] = ((unsigned)o < (unsigned)L) ? ai[o] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < 3; ++u) v[u] = fma(-xi, av[u], v[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int n = n0 + tid + WG * u;
-                if (n < N) {
-                    if (rout) rout[n] = v[u];
-                    cs = fma(v[u], v[u], cs);
-                }
-            }
-        }
-        if (rout && tid < TRI(d + 1)) rout[N + tid] = tid < TRI(d) ? sl->Lf[tid] : sl->y[tid - TRI(d)];
-        cs = wave_sum(cs);
-        if (lane == 63) sl->wsum[wave] = cs;
-        __syncthreads();
-        if (tid == 0) {
-            a.node_pos[cid] = p_sel;
-            a.node_atom[cid] = k_sel;
-            a.node_mse[cid] = (sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3]) / (double)N;
-        }
-        if (a.node_coef && tid < a.Kmax)
-            a.node_coef[cid * a.Kmax + tid] =
-                tid <= d ? sl->x[tid] + (tid < d ? sl->coefpar[tid] : 0.0) : 0.0;
+        child_solve_and_write(a, sl, r64, s, jc, cid);
 
         PROF_MARK(6);
         // ---- suppress the chosen atom's similarity disk for the next sibling ----------------------
@@ -886,6 +920,214 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
         }
         __syncthreads();
         PROF_MARK(7);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the tiled level kernel: dictionaries with more than 144 atoms and/or more than 256 positions
+// ------------------------------------------------------------------------------------------------
+// Same node semantics as mmp_level_kernel, but the (P x K) correlation matrix no longer fits one
+// workgroup's registers: it is produced unit by unit (unit = 256 positions x one 144-atom bank tile)
+// and never stored.  Per sibling: sweep 1 keeps the fp32 maximum of every unit (after suppression by
+// the earlier siblings, read from the similarity table), sweep 2 recomputes only the units whose
+// maximum reaches the candidate band and collects the candidates; then the shared fp64 re-score /
+// least-squares path runs.  For siblings after the first, the unsuppressed unit maxima of the first
+// sweep are upper bounds, so units that cannot reach the running maximum are skipped.
+#define MAX_UNITS 2048
+struct TiledLds {
+    float tmax0[MAX_UNITS];        // unsuppressed unit maxima (first sibling's sweep)
+    float tcur[MAX_UNITS];         // unit maxima of the current sibling's sweep (-inf = skipped)
+    int sib_pos[CSC_MAX_CONNECTIONS], sib_atom[CSC_MAX_CONNECTIONS];
+};
+
+__device__ __forceinline__ void load_tile_meta(const LevelArgs& a, NodeLds* sl, int tl) {
+    const int tid = threadIdx.x;
+    const int32_t* m = a.meta + (size_t)tl * META_INTS;
+    if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)m[CSC_TILE_COLS + tid - 192];
+    if (tid < CSC_TILE_COLS) sl->perm[tid] = m[tid];
+    __syncthreads();
+}
+
+// GEMM of one unit + masking of the entries outside the matrix + suppression by the first t siblings.
+// Returns the lane's maximum over its unsuppressed entries; lane_supp tells whether it holds a
+// suppressed (value 0) one.
+__device__ __forceinline__ float unit_correlations(const LevelArgs& a, NodeLds* sl, const TiledLds* tl2,
+                                                   const float* r32, float* slab, int rb, int tile, int t,
+                                                   int (&permv)[NT], f32x4 (&acc)[MT][NT], bool& lane_supp) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int K = a.K, P = a.P, W = a.W;
+    const int nslab = (a.L + SLAB - 1) / SLAB;
+    load_tile_meta(a, sl, tile);
+    corr_tile_gemm(a.bank32t + (size_t)tile * nslab * SLABF, sl->masks, nslab,
+                   r32 + rb * CSC_TILE_ROWS + 64 * wave + lr + lq, slab, acc);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) permv[ni] = sl->perm[16 * ni + lr];
+    const int prow = rb * CSC_TILE_ROWS + 64 * wave + 4 * lq;       // + 16*mi + rg
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+        if (rb * CSC_TILE_ROWS + 64 * wave + 16 * mi + 15 >= P) {      // wave-uniform
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    if (prow + 16 * mi + rg >= P) acc[mi][ni][rg] = -INFINITY;
+        }
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+        if (__ballot(permv[ni] < 0)) {                               // wave-uniform
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    if (permv[ni] < 0) acc[mi][ni][rg] = -INFINITY;
+        }
+    lane_supp = false;
+    for (int q = 0; q < t; ++q) {
+        const int dpb = prow - tl2->sib_pos[q] + P - 1;              // bit index of (mi, rg) = (0, 0); >= 0
+        const int w0 = dpb >> 5, b0 = dpb & 31;
+        const uint32_t* srow = a.sim_bits + (size_t)tl2->sib_atom[q] * K * W;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            const uint32_t* row = srow + (size_t)max(permv[ni], 0) * W;
+            const uint32_t wd0 = row[min(w0, W - 1)], wd1 = row[min(w0 + 1, W - 1)], wd2 = row[min(w0 + 2, W - 1)];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int off = b0 + 16 * mi + rg;               // < 32 + 52
+                    const uint32_t wd = off < 32 ? wd0 : (off < 64 ? wd1 : wd2);
+                    const bool hit = ((wd >> (off & 31)) & 1u) && acc[mi][ni][rg] > -INFINITY;
+                    acc[mi][ni][rg] = hit ? __uint_as_float(SUPP_BITS) : acc[mi][ni][rg];
+                    lane_supp |= hit;
+                }
+        }
+    }
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) lmax = fmaxf(lmax, acc[mi][ni][rg]);
+    return lmax;
+}
+
+__global__ __launch_bounds__(WG, 2) void mmp_level_tiled_kernel(const LevelArgs a) {
+    extern __shared__ double lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int N = a.N, K = a.K, Lp = a.Lp, P = a.P, d = a.depth;
+    const int ntile = (K + CSC_TILE_COLS - 1) / CSC_TILE_COLS;
+    const int nrb = (P + CSC_TILE_ROWS - 1) / CSC_TILE_ROWS;
+    const int nunits = ntile * nrb;
+
+    const int Npad = (N + 3) & ~3;
+    const int R32 = nrb * CSC_TILE_ROWS + Lp + 4;
+    float* slab = reinterpret_cast<float*>(lds_raw);                  // [2][SLABF]
+    double* r64 = lds_raw + SLABF;                                    // [Npad]
+    float* r32 = reinterpret_cast<float*>(r64 + Npad);                // [R32]
+    NodeLds* sl = reinterpret_cast<NodeLds*>(r32 + ((R32 + 3) & ~3));
+    TiledLds* tl2 = reinterpret_cast<TiledLds*>(sl + 1);
+
+    const int Fd = a.ts.F[d], Fc = a.ts.F[d + 1];
+    const size_t s = blockIdx.x / Fd;
+    const int j = (int)(blockIdx.x - s * Fd);
+    const int stride = a.ts.pw[d];
+    int nch = 0;
+    for (int r = 0; r < a.connections; ++r) {
+        if ((long long)j + (long long)r * stride < Fc) ++nch; else break;
+    }
+    const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
+    const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j);
+
+    f32x4 acc[MT][NT];
+    int permv[NT];
+    for (int t = 0; t < nch; ++t) {
+        // ---- sweep 1: unit maxima ------------------------------------------------------------------
+        float gmax = -INFINITY;                                       // workgroup-uniform
+        for (int u = 0; u < nunits; ++u) {
+            if (t > 0 && fmaxf(tl2->tmax0[u], 0.f) < gmax - delta) {   // cannot reach the band (uniform)
+                if (tid == 0) tl2->tcur[u] = -INFINITY;
+                continue;
+            }
+            bool lane_supp;
+            const float lmax = unit_correlations(a, sl, tl2, r32, slab, u / ntile, u % ntile, t, permv, acc, lane_supp);
+            const float bv = wave_max(lane_supp ? fmaxf(lmax, 0.f) : lmax);
+            if (lane == 63) sl->wmax[wave] = bv;
+            __syncthreads();
+            const float m = fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
+            if (tid == 0) {
+                tl2->tcur[u] = m;
+                if (t == 0) tl2->tmax0[u] = m;
+            }
+            gmax = fmaxf(gmax, m);
+            __syncthreads();                                          // wmax is rewritten by the next unit
+        }
+        // ---- sweep 2: candidates from the units that reach the band --------------------------------------
+        const float tau = gmax - delta;
+        const bool zero_band = (0.f >= tau);
+        if (tid == 0) sl->cand_cnt = 0;
+        __syncthreads();
+        int first_supp = 0x7fffffff, bi = 0x7fffffff;
+        for (int u = 0; u < nunits; ++u) {
+            if (!(tl2->tcur[u] >= tau) && !zero_band) continue;        // uniform
+            bool lane_supp;
+            const int rb = u / ntile;
+            const float lmax = unit_correlations(a, sl, tl2, r32, slab, rb, u % ntile, t, permv, acc, lane_supp);
+            const int rowK = (rb * CSC_TILE_ROWS + 64 * wave + 4 * lq) * K;
+            if (lmax >= tau) {
+                uint32_t mk[5] = {0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                        for (int ni = 0; ni < NT; ++ni) {
+                            const int e = (4 * mi + rg) * NT + ni;
+                            mk[e >> 5] |= (acc[mi][ni][rg] >= tau) ? (1u << (e & 31)) : 0u;
+                        }
+#pragma unroll
+                for (int w = 0; w < 5; ++w) {
+                    uint32_t mm = mk[w];
+                    while (mm) {
+                        const int e = 32 * w + __builtin_ctz(mm);
+                        mm &= mm - 1;
+                        const int r = e / NT, ni = e - r * NT;
+                        const int idx = rowK + (16 * (r >> 2) + (r & 3)) * K + sl->perm[16 * ni + lr];
+                        const int slot = atomicAdd(&sl->cand_cnt, 1);
+                        if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
+                        bi = min(bi, idx);
+                    }
+                }
+            }
+            if (zero_band) {
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                        for (int ni = 0; ni < NT; ++ni)
+                            if (is_supp(acc[mi][ni][rg]))
+                                first_supp = min(first_supp, rowK + (16 * mi + rg) * K + permv[ni]);
+            }
+            __syncthreads();                                          // perm / masks are rewritten by the next unit
+        }
+        if (zero_band) {
+            first_supp = wave_min(first_supp);
+            if (lane == 0) sl->wsupp[wave] = first_supp;
+        }
+        // overflow fallback (never seen on real data): lowest index among the band entries
+        bi = wave_min(bi);
+        if (lane == 0) sl->widx[wave] = bi;
+        __syncthreads();
+        const int ncand_raw = sl->cand_cnt;
+        rescore_and_choose(a, sl, r64, ncand_raw, zero_band);
+        const int jc = j + t * stride;
+        const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
+        if (tid == 0) { tl2->sib_pos[t] = sl->sup_pos[d]; tl2->sib_atom[t] = sl->sup_atom[d]; }
+        child_solve_and_write(a, sl, r64, s, jc, cid);
+        __syncthreads();
     }
 }
 
@@ -1100,9 +1342,10 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
     if (connections > 1 && !d_sim_bits) FAIL(-1, "csc_mmpdf_batch: similarity table required when connections > 1");
     if (K <= 0 || L <= 0 || S < 0) FAIL(-1, "csc_mmpdf_batch: bad sizes");
     if (P <= 0) FAIL(-6, "signal length %d shorter than atom length %d", N, L);
-    if (K > CSC_TILE_COLS || P > CSC_TILE_ROWS)
-        FAIL(-9, "dictionary (K = %d, P = %d) exceeds the register-resident tile (%d x %d)", K, P,
-             CSC_TILE_COLS, CSC_TILE_ROWS);
+    const bool tiled = (K > CSC_TILE_COLS || P > CSC_TILE_ROWS);      // correlation matrix larger than one register tile
+    const int nrb = (P + CSC_TILE_ROWS - 1) / CSC_TILE_ROWS;
+    if (tiled && (long long)n_tiles(K) * nrb > MAX_UNITS)
+        FAIL(-9, "dictionary (K = %d, P = %d) exceeds %d (256 x 144) units per node", K, P, MAX_UNITS);
     if (n_slabs(L) > MAX_SLABS) FAIL(-8, "atom length %d exceeds %d", L, MAX_SLABS * SLAB);
     if (max_sparsity > P * K) FAIL(-2, "max_sparsity exceeds the number of activations");
     const size_t need = csc_mmpdf_workspace_bytes(S, N, max_sparsity, connections, branches);
@@ -1111,13 +1354,15 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
     const int Lp = n_slabs(L) * SLAB;                      // residual window zero-padded to whole slabs
     const int W = csc_sim_words(N, L);
     size_t lds = level_lds_bytes(N, Lp);
+    if (tiled) lds += (size_t)(nrb - 1) * CSC_TILE_ROWS * 4 + sizeof(TiledLds);
 #ifdef CSC_PHASE_PROF
     if (getenv("CSC_EXTRA_LDS")) lds += (size_t)atoi(getenv("CSC_EXTRA_LDS"));   // force 1 workgroup per CU
 #endif
     if (lds > 150 * 1024) FAIL(-8, "signal too long for the LDS-resident node kernel (%zu B)", lds);
-    if ((size_t)K * (W + 1) * 4 > 2 * SLABF * 4) FAIL(-8, "similarity row does not fit the slab buffer");
+    if (!tiled && (size_t)K * (W + 1) * 4 > 2 * SLABF * 4) FAIL(-8, "similarity row does not fit the slab buffer");
     clear_stale_error();
-    hipFuncSetAttribute((const void*)mmp_level_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(tiled ? (const void*)mmp_level_tiled_kernel : (const void*)mmp_level_kernel,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 
     double* ws[2] = {static_cast<double*>(d_workspace), static_cast<double*>(d_workspace) + need / 16};
     hipStream_t st = (hipStream_t)stream;
@@ -1134,7 +1379,8 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
         const size_t grid = (size_t)S * ts.F[d];
         if (grid > 0x7fffffffULL) FAIL(-11, "batch too large for one launch (%zu workgroups)", grid);
         const int span = timer_begin(st, d);
-        hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
+        if (tiled) hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
+        else hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
         timer_end(st, span);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) FAIL((int)e, "mmp_level_kernel launch failed at level %d: %s", d, hipGetErrorString(e));

@@ -1,0 +1,96 @@
+"""GPU parity of the TILED level kernel (dictionaries beyond one 256 x 144 register tile).
+
+* BASELINE config 3: the 9570-atom dictionary (L = 518, N = 777, P = 260) against whole-tree dumps
+  generated from the reference (tests/golden/make_golden_large.py); the 40 MB bank is rebuilt here and
+  pinned by its sha256.
+* a 2-row-block x 3-column-tile dictionary against the CPU oracle with 3 connections / 10 branches, so
+  that sibling suppression, pruning and candidate collection cross unit boundaries.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_json
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_nodes(res, s, nodes, c):
+    for path, node in nodes.items():
+        pos, atom, mse = node[0], node[1], node[2]
+        digits = [int(x) for x in path.split("-")]
+        nid = res.node_id(len(digits), sum((o - 1) * c ** i for i, o in enumerate(digits)))
+        got = (int(res.node_pos[s, nid]), int(res.node_atom[s, nid]))
+        assert got == (pos, atom), (s, path, got, (pos, atom))
+        assert abs(res.node_mse[s, nid] - mse) <= 1e-9 * mse, (s, path)
+
+
+@pytest.fixture(scope="module")
+def large_dic():
+    import csc_amd
+    return csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.0005), np.arange(0.010, 0.036, 0.0003), [1])
+
+
+def test_config3_trees_vs_reference(large_dic):
+    ref = load_json("large.json")
+    z = np.load(os.path.join(GOLDEN, "large.npz"))
+    assert (len(large_dic), large_dic.getAtomsLength()) == (ref["K"], ref["L"]) == (9570, 518)
+    bank = large_dic.getLocalDictionary()
+    assert hashlib.sha256(np.ascontiguousarray(bank).tobytes()).hexdigest() == ref["bank_sha256"]
+    sigs = z["signals"]
+    assert sigs.shape[1] == ref["N"] == 777
+    res, _ = large_dic._batch(sigs, 5, 3, 3, 0.8, want_coef=True)
+    assert res.stats[0] == 0 and res.stats[1] == 0
+    for s, tree in enumerate(ref["c3_K5_B3_thr0.8"]):
+        assert len(tree["nodes"]) == 15
+        _check_nodes(res, s, tree["nodes"], 3)
+        rec = tree["record"]
+        leaf = int(res.rec_leaf[s, 4, 0])
+        assert abs(res.rec_mse[s, 4] - rec["mse"]) <= 1e-9 * rec["mse"]
+        if res.path_str(5, leaf) == rec["path"]:
+            got = large_dic._sparvar_records(res, s, 0.0)[4]
+            assert got["atoms"] == rec["atoms"]
+    # correlations of the stand-alone entry point on the same dictionary (67 column tiles, 2 row blocks)
+    c = large_dic.device_bank().correlate(sigs[:1]).cpu().numpy()[0]
+    win = np.lib.stride_tricks.sliding_window_view(sigs[0], 518)
+    want = win @ bank.T
+    assert c.shape == want.shape == (260, 9570)
+    assert np.abs(c - want).max() <= 3e-6 * np.linalg.norm(sigs[0])
+
+
+def test_multi_unit_tree_vs_oracle():
+    """K = 330 atoms (3 column tiles, the last partly filled), P = 300 positions (2 row blocks),
+    connections 3, branches 10, sparsity 4, dissimilarity 0.7: every node against the CPU oracle."""
+    import csc_amd
+    from oracle import csc_oracle as O
+    b, y = np.arange(0.005, 0.06, 0.0025), np.arange(0.010, 0.036, 0.0018)
+    d = csc_amd.ZSDictionary.from_values(b, y, [1])
+    od = O.OracleDictionary(b, y, [1])
+    assert np.array_equal(d.getLocalDictionary(), od.bank)
+    K, L = od.K, od.L
+    assert K == 22 * 15
+    N = L + 299
+    rng = np.random.default_rng(5)
+    sigs = []
+    for i in range(6):
+        sig = 0.02 * rng.standard_normal(N)
+        for _ in range(3):
+            sig[rng.integers(0, 300):][:L] += rng.uniform(0.5, 1.5) * od.bank[rng.integers(K)]
+        sigs.append(sig)
+    sigs = np.array(sigs)
+    res, _ = d._batch(sigs, 4, 3, 10, 0.7, want_coef=True)
+    assert res.level_sizes == [3, 9, 10, 10] and res.stats[0] == 0
+    for s in range(len(sigs)):
+        t = O.OracleTree(od, sigs[s], 4, 3, 0.7, "direct")
+        t.run(10)
+        nodes = t.all_nodes()
+        assert len(nodes) == 32
+        _check_nodes(res, s, nodes, 3)
+    # OMP on the same dictionary: amplitudes against the oracle's projection
+    res1, _ = d._batch(sigs[:2], 3, 1, 1, 1.0, want_coef=True)
+    for s in range(2):
+        sup = res1.branch(s, 3, 0)
+        _, coef = od.project(sigs[s], sup, N, "direct")
+        assert np.allclose(res1.node_coef[s, res1.node_id(3, 0), :3], coef, rtol=1e-9)
