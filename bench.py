@@ -124,9 +124,11 @@ def main():
     from csc_amd import _lib
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run (also with 1 rank)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     bank = dic.device_bank()
     K, L = bank.K, bank.L
@@ -150,18 +152,18 @@ def main():
     pcie_s = time.time() - t0
     del d_sig2
 
-    gathered = [torch.empty_like(out["rec_buf"]) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = [torch.empty_like(out["rec_buf"]) for _ in range(world)] if (use_dist and rank == 0) else None
 
     def step():
         bank.mmpdf_launch(d_sig, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY, want_coef=False, out=out)
-        if world > 1:
-            dist.gather(out["rec_buf"], gathered, dst=0)
+        if use_dist:
+            dist.gather(out["rec_buf"], gathered, dst=0)      # the ONE collective of the path: sparVar records
 
     for _ in range(a.warmup):
         step()
     timer = _lib.LevelTimer(capacity=a.steps * MAX_SPARSITY)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -169,7 +171,7 @@ def main():
         for _ in range(a.steps):
             step()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
@@ -178,7 +180,7 @@ def main():
     stats = out["stats"].cpu().numpy().tolist()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -230,7 +232,9 @@ def main():
             "fp32_argmax_fallbacks": stats[0], "duplicate_columns": stats[1],
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
+        if rank == 0:      # the gathered buffers hold every rank's records, rank 0's own first
+            assert torch.equal(gathered[0], out["rec_buf"])
         dist.barrier()
         dist.destroy_process_group()
 

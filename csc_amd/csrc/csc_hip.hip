@@ -243,6 +243,49 @@ __device__ __forceinline__ void corr_tile_gemm(const float* __restrict__ tile, c
     }
 }
 
+// Remainder row block (at most 16 valid positions, e.g. rows 256..259 of P = 260): one 16-row tile,
+// the column tiles dealt round-robin to the 4 waves (wave w owns ni = w, w+4, w+8), so the pass costs
+// about 1/16 of a full unit instead of a whole one.  Only acc[0][owned ni] is written.
+__device__ __forceinline__ void corr_rem_gemm(const float* __restrict__ tile, const uint32_t* masks, int nslab,
+                                              const float* r32row, float* slab, f32x4 (&acc)[MT][NT]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[0][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint32_t m = __builtin_amdgcn_readfirstlane(masks[0]);
+    if (m) stage_blocks(tile, slab, __builtin_ctz(m), wave, lane);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        uint32_t mn = 0;
+        if (s + 1 < nslab) {
+            mn = __builtin_amdgcn_readfirstlane(masks[s + 1]);
+            if (mn) stage_blocks(tile + (size_t)(s + 1) * SLABF, slab + ((s + 1) & 1) * SLABF, __builtin_ctz(mn), wave, lane);
+        }
+        if (m) {
+            const int ni0 = __builtin_ctz(m);
+            const float* ra = r32row + s * SLAB;
+            const float* sb = slab + (s & 1) * SLABF + lq * 16 + lr;
+            float af[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) af[ks] = ra[4 * ks];
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                if ((ni & 3) == wave && ni >= ni0) {
+                    float bf[8];
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) bf[ks] = sb[ni * BLKF + 64 * ks];
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks)
+                        acc[0][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks], bf[ks], acc[0][ni], 0, 0, 0);
+                }
+            }
+        }
+        m = mn;
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // bank packing: [K][L] f64 -> column tiles sorted by support, blocked [tile][slab][ni][32][16] f32
 // ------------------------------------------------------------------------------------------------
@@ -953,20 +996,35 @@ __device__ __forceinline__ void load_tile_meta(const LevelArgs& a, NodeLds* sl, 
 // suppressed (value 0) one.
 __device__ __forceinline__ float unit_correlations(const LevelArgs& a, NodeLds* sl, const TiledLds* tl2,
                                                    const float* r32, float* slab, int rb, int tile, int t,
-                                                   int (&permv)[NT], f32x4 (&acc)[MT][NT], bool& lane_supp) {
+                                                   int (&permv)[NT], f32x4 (&acc)[MT][NT], bool& lane_supp,
+                                                   int& rowbase_out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int K = a.K, P = a.P, W = a.W;
     const int nslab = (a.L + SLAB - 1) / SLAB;
     load_tile_meta(a, sl, tile);
-    corr_tile_gemm(a.bank32t + (size_t)tile * nslab * SLABF, sl->masks, nslab,
-                   r32 + rb * CSC_TILE_ROWS + 64 * wave + lr + lq, slab, acc);
+    const bool rem = (P - rb * CSC_TILE_ROWS) <= 16;                 // uniform: a one-tile remainder block
+    const int rowbase = rb * CSC_TILE_ROWS + (rem ? 0 : 64 * wave);
+    if (rem) {
+        corr_rem_gemm(a.bank32t + (size_t)tile * nslab * SLABF, sl->masks, nslab,
+                      r32 + rb * CSC_TILE_ROWS + lr + lq, slab, acc);
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            if ((ni & 3) != wave) acc[0][ni] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int mi = 1; mi < MT; ++mi) acc[mi][ni] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+    } else {
+        corr_tile_gemm(a.bank32t + (size_t)tile * nslab * SLABF, sl->masks, nslab,
+                       r32 + rowbase + lr + lq, slab, acc);
+    }
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) permv[ni] = sl->perm[16 * ni + lr];
-    const int prow = rb * CSC_TILE_ROWS + 64 * wave + 4 * lq;       // + 16*mi + rg
+    const int prow = rowbase + 4 * lq;                               // + 16*mi + rg
+    rowbase_out = rowbase;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
-        if (rb * CSC_TILE_ROWS + 64 * wave + 16 * mi + 15 >= P) {      // wave-uniform
+        if (rowbase + 16 * mi + 15 >= P) {                           // wave-uniform
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
@@ -1052,7 +1110,8 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled_kernel(const LevelArgs 
                 continue;
             }
             bool lane_supp;
-            const float lmax = unit_correlations(a, sl, tl2, r32, slab, u / ntile, u % ntile, t, permv, acc, lane_supp);
+            int rowbase;
+            const float lmax = unit_correlations(a, sl, tl2, r32, slab, u / ntile, u % ntile, t, permv, acc, lane_supp, rowbase);
             const float bv = wave_max(lane_supp ? fmaxf(lmax, 0.f) : lmax);
             if (lane == 63) sl->wmax[wave] = bv;
             __syncthreads();
@@ -1073,9 +1132,9 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled_kernel(const LevelArgs 
         for (int u = 0; u < nunits; ++u) {
             if (!(tl2->tcur[u] >= tau) && !zero_band) continue;        // uniform
             bool lane_supp;
-            const int rb = u / ntile;
-            const float lmax = unit_correlations(a, sl, tl2, r32, slab, rb, u % ntile, t, permv, acc, lane_supp);
-            const int rowK = (rb * CSC_TILE_ROWS + 64 * wave + 4 * lq) * K;
+            int rowbase;
+            const float lmax = unit_correlations(a, sl, tl2, r32, slab, u / ntile, u % ntile, t, permv, acc, lane_supp, rowbase);
+            const int rowK = (rowbase + 4 * lq) * K;
             if (lmax >= tau) {
                 uint32_t mk[5] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
