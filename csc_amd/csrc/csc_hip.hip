@@ -656,6 +656,8 @@ __device__ __forceinline__ void rescore_and_choose(const LevelArgs& a, NodeLds* 
             chosen = besti;
         }
         if (a.stats) atomicAdd(&a.stats[2], ncand);
+        // all-NaN correlations (NaN / Inf in the signal): np.argmax of an all-NaN array is 0 (src/csc/mmp.py:227)
+        if ((unsigned)chosen >= (unsigned)(a.P * K)) chosen = 0;
         sl->chosen = chosen;
         sl->sup_pos[d] = chosen / K;
         sl->sup_atom[d] = chosen - (chosen / K) * K;

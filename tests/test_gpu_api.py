@@ -262,3 +262,45 @@ def test_gather_records_nccl_world1(dic, golden_signals):
         assert np.array_equal(res.node_pos, ref.node_pos) and np.array_equal(res.rec_mse, ref.rec_mse)
     finally:
         dist.destroy_process_group()
+
+
+def test_nan_and_inf_signals_do_not_fault(dic, golden_signals):
+    """NaN / Inf samples: the reference's correlations become all-NaN and np.argmax returns 0; here the
+    selection falls back to activation 0 as well, MSE is NaN, and the neighbours in the batch are untouched."""
+    sigs = golden_signals["signals"][:4].copy()
+    sigs[1, 100] = np.nan
+    sigs[2, 5] = np.inf
+    bank = dic.device_bank()
+    res = bank.mmpdf_batch(sigs, 3, 3, 3, 0.8)
+    ref = bank.mmpdf_batch(golden_signals["signals"][:4], 3, 3, 3, 0.8)
+    for s in (0, 3):
+        assert np.array_equal(res.node_pos[s], ref.node_pos[s]) and np.array_equal(res.node_mse[s], ref.node_mse[s])
+    assert np.isnan(res.node_mse[1]).all() and res.node_pos[1, 0] == 0 and res.node_atom[1, 0] == 0
+    assert not np.isfinite(res.node_mse[2]).any()
+    assert (res.node_pos >= 0).all() and (res.node_pos < 247).all() and (res.node_atom >= 0).all() and (res.node_atom < 143).all()
+
+
+def test_odd_shapes_vs_oracle():
+    """tiny dictionary (6 atoms), P = 2 and P = 1 positions, atom length not a multiple of 32"""
+    import csc_amd
+    from oracle import csc_oracle as O
+    b, y = [0.01, 0.03], [0.012, 0.02, 0.03]
+    d = csc_amd.ZSDictionary.from_values(b, y, [1])
+    od = O.OracleDictionary(b, y, [1])
+    L = od.L
+    rng = np.random.default_rng(11)
+    for P in (1, 2, 37):
+        N = L + P - 1
+        sigs = rng.standard_normal((3, N)) * 0.05
+        for s in range(3):
+            sigs[s, rng.integers(0, P):][:L] += od.bank[rng.integers(6)]
+        Kx = min(3, P * 6)
+        res, _ = d._batch(sigs, Kx, 2, 3, 0.8, want_coef=True)
+        for s in range(3):
+            t = O.OracleTree(od, sigs[s], Kx, 2, 0.8, "direct")
+            t.run(3)
+            for path, (pos, atom, mse) in t.all_nodes().items():
+                digits = [int(x) for x in path.split("-")]
+                nid = res.node_id(len(digits), sum((o - 1) * 2 ** i for i, o in enumerate(digits)))
+                assert (int(res.node_pos[s, nid]), int(res.node_atom[s, nid])) == (pos, atom), (P, s, path)
+                assert abs(res.node_mse[s, nid] - mse) <= 1e-9 * mse + 1e-30
