@@ -74,6 +74,7 @@ struct LevelArgs {
     int Kmax, connections, NN;
     int NS;               // doubles per node in the workspace: N residual + TRI(Kmax) Cholesky factor
     int stagger_ticks;    // > 0: initial phase offset between the two workgroups of a CU (100 MHz ticks)
+    int mode;             // 0: orthogonal (OMP / MMP-DF least squares); 1: plain matching pursuit
     const double* resid_in;   // d == 0: signals [S][N]; else [S][F[d]][NS]
     double* resid_out;        // [S][F[d+1]][NS] or nullptr (children are final leaves)
     int32_t* node_pos; int32_t* node_atom; double* node_mse; double* node_coef;
@@ -674,6 +675,48 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
     const int N = a.N, L = a.L, d = a.depth;
     const int p_sel = sl->sup_pos[d], k_sel = sl->sup_atom[d];
     const int Fc = a.ts.F[d + 1];
+    if (a.mode == 1) {
+        // ---- plain matching pursuit (src/csc/dictionary.py:787-805) ----------------------------------------
+        // activation_mask[idx] += <a_sel, r>; approx = conv(mask * mask): the reference applies the mask to
+        // itself (:803), so an activation weighs mask^2.  node_coef holds the mask value per support slot
+        // (first occurrence of a re-selected activation accumulates, later slots stay 0).
+        {
+            const double* an = a.bank64 + (size_t)k_sel * L;
+            double v = dot_range<64>(an, r64 + p_sel, 0, L, lane);
+            v = wave_sum(v);
+            if (tid == 63) {
+                int slot = d;
+                for (int q = d - 1; q >= 0; --q)
+                    if (sl->sup_pos[q] == p_sel && sl->sup_atom[q] == k_sel) slot = q;
+                const double m_old = slot < d ? sl->coefpar[slot] : 0.0;
+                const double m_new = m_old + v;
+                for (int q = 0; q <= d; ++q) sl->x[q] = q < d ? sl->coefpar[q] : 0.0;   // mask values out
+                sl->x[slot] = m_new;
+                sl->g[0] = m_new * m_new - m_old * m_old;            // weight change of the placed atom
+            }
+        }
+        __syncthreads();
+        const double dw = sl->g[0];
+        double* rout = a.resid_out ? a.resid_out + (s * Fc + jc) * (size_t)a.NS : nullptr;
+        const double* an = a.bank64 + (size_t)k_sel * L;
+        double cs = 0.0;
+        for (int n = tid; n < N; n += WG) {
+            const int o = n - p_sel;
+            const double v = r64[n] - (((unsigned)o < (unsigned)L) ? dw * an[o] : 0.0);
+            if (rout) rout[n] = v;
+            cs = fma(v, v, cs);
+        }
+        cs = wave_sum(cs);
+        if (lane == 63) sl->wsum[wave] = cs;
+        __syncthreads();
+        if (tid == 0) {
+            a.node_pos[cid] = p_sel;
+            a.node_atom[cid] = k_sel;
+            a.node_mse[cid] = (sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3]) / (double)N;
+        }
+        if (a.node_coef && tid < a.Kmax) a.node_coef[cid * a.Kmax + tid] = tid <= d ? sl->x[tid] : 0.0;
+        return;
+    }
     // ---- one new Gram column (fp64 dots, one per half-wave) ------------------------------------------
     {
         const int hw = tid >> 5, hl = tid & 31;
@@ -1386,20 +1429,20 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
     return 2 * (size_t)S * fmax * (N + TRI(max_sparsity)) * sizeof(double);
 }
 
-int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
-                    int K, int L, const double* d_signals, int S, int N,
-                    int max_sparsity, int connections, int branches,
-                    void* d_workspace, size_t workspace_bytes,
-                    int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse,
-                    double* d_node_coef, double* d_rec_mse, int32_t* d_rec_leaf,
-                    int32_t* d_rec_sel, int32_t* d_stats, void* stream) {
+static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
+                      int K, int L, const double* d_signals, int S, int N,
+                      int max_sparsity, int connections, int branches,
+                      void* d_workspace, size_t workspace_bytes,
+                      int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse,
+                      double* d_node_coef, double* d_rec_mse, int32_t* d_rec_leaf,
+                      int32_t* d_rec_sel, int32_t* d_stats, void* stream) {
     TreeShape ts;
     const int NN = make_shape(max_sparsity, connections, branches, &ts);
     if (NN < 0) return NN;
     const int P = N - L + 1;
     if (S == 0) return 0;
     if (!d_bank32t || !d_bank64 || !d_signals || !d_node_pos || !d_node_atom || !d_node_mse)
-        FAIL(-1, "csc_mmpdf_batch: null pointer");
+        FAIL(-1, "csc_mmpdf_batch / csc_mp_batch: null pointer");
     if (connections > 1 && !d_sim_bits) FAIL(-1, "csc_mmpdf_batch: similarity table required when connections > 1");
     if (K <= 0 || L <= 0 || S < 0) FAIL(-1, "csc_mmpdf_batch: bad sizes");
     if (P <= 0) FAIL(-6, "signal length %d shorter than atom length %d", N, L);
@@ -1432,7 +1475,7 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
         a.bank32t = d_bank32t; a.meta = bank_meta(d_bank32t, K, L); a.bank64 = d_bank64; a.sim_bits = d_sim_bits;
         a.K = K; a.L = L; a.Lp = Lp; a.N = N; a.P = P; a.W = W;
         a.depth = d; a.Kmax = max_sparsity; a.connections = connections; a.NN = NN;
-        a.NS = N + TRI(max_sparsity); a.stagger_ticks = stagger_ticks();
+        a.NS = N + TRI(max_sparsity); a.stagger_ticks = stagger_ticks(); a.mode = mode;
         a.resid_in = (d == 0) ? d_signals : ws[d & 1];
         a.resid_out = (d + 1 < max_sparsity) ? ws[(d + 1) & 1] : nullptr;
         a.node_pos = d_node_pos; a.node_atom = d_node_atom; a.node_mse = d_node_mse; a.node_coef = d_node_coef;
@@ -1454,6 +1497,28 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
         if (e != hipSuccess) FAIL((int)e, "reduce_kernel launch failed: %s", hipGetErrorString(e));
     }
     return 0;
+}
+
+int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
+                    int K, int L, const double* d_signals, int S, int N,
+                    int max_sparsity, int connections, int branches,
+                    void* d_workspace, size_t workspace_bytes,
+                    int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse,
+                    double* d_node_coef, double* d_rec_mse, int32_t* d_rec_leaf,
+                    int32_t* d_rec_sel, int32_t* d_stats, void* stream) {
+    return run_levels(0, d_bank32t, d_bank64, d_sim_bits, K, L, d_signals, S, N, max_sparsity, connections,
+                      branches, d_workspace, workspace_bytes, d_node_pos, d_node_atom, d_node_mse, d_node_coef,
+                      d_rec_mse, d_rec_leaf, d_rec_sel, d_stats, stream);
+}
+
+int csc_mp_batch(const float* d_bank32t, const double* d_bank64, int K, int L, const double* d_signals,
+                 int S, int N, int iterations, void* d_workspace, size_t workspace_bytes,
+                 int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse, double* d_node_mask,
+                 int32_t* d_stats, void* stream) {
+    if (!d_node_mask && S > 0) FAIL(-1, "csc_mp_batch: d_node_mask is required");
+    return run_levels(1, d_bank32t, d_bank64, nullptr, K, L, d_signals, S, N, iterations, 1, 1, d_workspace,
+                      workspace_bytes, d_node_pos, d_node_atom, d_node_mse, d_node_mask, nullptr, nullptr,
+                      nullptr, d_stats, stream);
 }
 
 int csc_project_batch(const double* d_bank64, int K, int L, const double* d_signals, int S, int N,

@@ -418,6 +418,129 @@ class CSCDictionary:
         return self._omp_sparvar_result(signal_dict, res, 0, dt)
 
     # ------------------------------------------------------------------------------------------
+    # plain matching pursuit (reference :764-996)
+    # ------------------------------------------------------------------------------------------
+    def _mp_batch(self, signals, iterations, sharded=False):
+        """-> (pos, atom, mse, mask) host arrays of csc_mp_batch, or None on ranks != 0 when sharded."""
+        from . import distributed as D
+        signals = np.ascontiguousarray(signals, dtype=np.float64)
+        if signals.ndim == 1:
+            signals = signals[None]
+        S, I = len(signals), int(iterations)
+        bank = self.device_bank()
+        lo, hi = D.shard_range(S, D.rank(), D.world_size()) if sharded else (0, S)
+        parts = [bank.mp_batch(signals[c0:min(hi, c0 + self.PIPELINE_CHUNK)], I)
+                 for c0 in range(lo, hi, self.PIPELINE_CHUNK)]
+        shapes, dts = [(I,), (I,), (I,), (I, I)], [np.int32, np.int32, np.float64, np.float64]
+        arrs = [np.concatenate([p[f] for p in parts]) if parts else np.zeros((0,) + shp, dt)
+                for f, (shp, dt) in enumerate(zip(shapes, dts))]
+        if not (sharded and D.is_distributed()):
+            return arrs
+        raw = np.concatenate([np.ascontiguousarray(a).reshape(hi - lo, -1).view(np.uint8) for a in arrs], axis=1)
+        raw = D.gather_records(raw, S)
+        if raw is None:
+            return None
+        out, at = [], 0
+        for shp, dt in zip(shapes, dts):
+            nb = int(np.prod(shp)) * np.dtype(dt).itemsize
+            out.append(np.ascontiguousarray(raw[:, at:at + nb]).view(dt).reshape((S,) + shp))
+            at += nb
+        return out
+
+    def _mp_state(self, pos, atom, mask, N):
+        """(approx, infos) from one iteration's state: approx = sum mask^2 atoms (the reference applies
+        the mask to itself, :803); atoms by descending mask value over np.where order (:808-823)."""
+        K = len(self.atoms)
+        flat = pos.astype(np.int64) * K + atom
+        acts = {}
+        for f, m in zip(flat, mask):
+            if m != 0:
+                acts[int(f)] = acts.get(int(f), 0.0) + float(m)
+        idx = np.array(sorted(acts), dtype=np.int64)
+        vals = np.array([acts[int(i)] for i in idx])
+        approx = np.zeros(N)
+        for i, v in zip(idx, vals):
+            approx[i // K:i // K + self.atoms_length] += v * v * self.atoms[i % K]()
+        order = np.argsort(vals)[::-1]
+        return approx, [self._info(i // K, i % K) for i in idx[order]]
+
+    @time_decorator
+    def mp(self, signal: np.ndarray, sparsity_level: int, verbose: bool = False) -> Tuple[np.ndarray, List[dict]]:
+        """(approx, infos) of convolutional matching pursuit (reference :764-825)."""
+        signal = np.asarray(signal, dtype=np.float64)
+        pos, atom, _, mask = self._mp_batch(signal, sparsity_level)
+        k = sparsity_level
+        return self._mp_state(pos[0, :k], atom[0, :k], mask[0, k - 1, :k], len(signal))
+
+    def _mp_result(self, sd, arrs, row, N):
+        pos, atom, mse, mask = arrs
+        k = len(sd["atoms"])
+        approx, infos = self._mp_state(pos[row, :k], atom[row, :k], mask[row, k - 1, :k], N)
+        return {"id": sd["id"], "mse": float(mse[row, k - 1]), "sparsity": len(infos), "approx": approx.tolist(),
+                "atoms": infos}
+
+    def _mp_sparvar_result(self, sd, arrs, row, N, delay):
+        pos, atom, mse, mask = arrs
+        I = pos.shape[1]
+        out = [{"mse": float(mse[row, k - 1]),
+                "atoms": self._mp_state(pos[row, :k], atom[row, :k], mask[row, k - 1, :k], N)[1],
+                "delay": delay * k / I} for k in range(1, I + 1)]
+        return {"id": sd["id"], "snr": sd["snr"], "results": out}
+
+    def mpFromDict(self, signal_dict: dict, verbose: bool = False) -> dict:
+        """{'id','mse','sparsity','approx','atoms'} (reference :827-845)."""
+        signal = np.asarray(signal_dict["signal"], dtype=np.float64)
+        return self._mp_result(signal_dict, self._mp_batch(signal, len(signal_dict["atoms"])), 0, len(signal))
+
+    def mpSparVarFromDict(self, signal_dict: dict, max_sparsity: int, verbose: bool = False) -> dict:
+        """One record per MP iteration 1..max_sparsity (reference :847-921)."""
+        signal = np.asarray(signal_dict["signal"], dtype=np.float64)
+        t0 = time.time()
+        arrs = self._mp_batch(signal, max_sparsity)
+        return self._mp_sparvar_result(signal_dict, arrs, 0, len(signal), time.time() - t0)
+
+    def _mp_pipeline(self, input_filename, output_filename, key, iterations, build, extra, verbose):
+        data = self._load_db(input_filename)
+        signals = data["signals"]
+        groups = {}
+        for i, sd in enumerate(signals):
+            groups.setdefault(key(sd), []).append(i)
+        out = [None] * len(signals)
+        for k, idxs in groups.items():
+            t0 = time.time()
+            arrs = self._mp_batch(np.array([signals[i]["signal"] for i in idxs], dtype=np.float64), iterations(k),
+                                  sharded=True)
+            if arrs is None:
+                out = None
+                continue
+            dt = (time.time() - t0) / max(1, len(idxs))
+            for row, i in enumerate(idxs):
+                out[i] = build(signals[i], arrs, row, k, dt)
+        if out is None:
+            return
+        results = {"source": input_filename, "date": get_today_date_str(), "algorithm": "Convolutional MP",
+                   "batchSize": data["batchSize"], "snrLevels": data["snrLevels"]}
+        results.update(extra)
+        results.update({"signalLength": data["signalLength"], "sparsityLevels": data["sparsityLevels"],
+                        "dictionary": str(self), "mp": out})
+        self._dump(results, output_filename)
+        if verbose:
+            print(f"MP Pipeline results saved in {output_filename}")
+
+    def mpPipelineFromDB(self, input_filename: str, output_filename: str, nb_cores: int, verbose=False):
+        """reference :923-957"""
+        self._mp_pipeline(input_filename, output_filename, lambda sd: (len(sd["signal"]), len(sd["atoms"])),
+                          lambda k: k[1], lambda sd, arrs, row, k, dt: self._mp_result(sd, arrs, row, k[0]), {},
+                          verbose)
+
+    def mpSparVarPipelineFromDB(self, input_filename: str, output_filename: str, nb_cores: int, max_sparsity: int,
+                                verbose=False):
+        """reference :959-996"""
+        self._mp_pipeline(input_filename, output_filename, lambda sd: len(sd["signal"]), lambda k: max_sparsity,
+                          lambda sd, arrs, row, k, dt: self._mp_sparvar_result(sd, arrs, row, k, dt),
+                          {"maxSparsityLevel": max_sparsity}, verbose)
+
+    # ------------------------------------------------------------------------------------------
     # MMP-DF (reference :1012-1152)
     # ------------------------------------------------------------------------------------------
     def mmpdf(self, signal: np.ndarray, sparsity_level: int, connections_level: int, dissimilarity: float,

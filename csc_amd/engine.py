@@ -195,6 +195,30 @@ class DeviceBank:
         return (coef.cpu().numpy(), mse.cpu().numpy(), approx.cpu().numpy() if want_approx else None,
                 int(stats[1].item()))
 
+    # ---- batched matching pursuit (mp / mpFromDict / mpSparVarFromDict) -----------------------------------
+    def mp_batch(self, signals, iterations):
+        """signals [S, N] -> host (pos [S, I], atom [S, I], mse [S, I], mask [S, I, I]); row i = state after
+        iteration i + 1, mask[s, i, q] = accumulated mask value of the q-th selection (csc_mp_batch)."""
+        sig = self._to_device(signals)
+        S, N = sig.shape
+        if N - self.L + 1 <= 0:
+            raise ValueError(f"signal length {N} shorter than atom length {self.L}")
+        I = int(iterations)
+        dev = self.device
+        with torch.cuda.device(dev):
+            ws_bytes = self.lib.csc_mmpdf_workspace_bytes(max(S, 1), N, I, 1, 1)
+            ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.float64, device=dev)
+            pos = torch.zeros((S, I), dtype=torch.int32, device=dev)
+            atom = torch.zeros((S, I), dtype=torch.int32, device=dev)
+            mse = torch.zeros((S, I), dtype=torch.float64, device=dev)
+            mask = torch.zeros((S, I, I), dtype=torch.float64, device=dev)
+            stats = torch.zeros(4, dtype=torch.int32, device=dev)
+            _lib.check(self.lib.csc_mp_batch(_ptr(self.bank32t), _ptr(self.bank64), self.K, self.L, _ptr(sig), S, N,
+                                             I, _ptr(ws), ws.numel() * 8, _ptr(pos), _ptr(atom), _ptr(mse),
+                                             _ptr(mask), _ptr(stats), _stream(dev)), "csc_mp_batch")
+            torch.cuda.synchronize(dev)
+        return pos.cpu().numpy(), atom.cpu().numpy(), mse.cpu().numpy(), mask.cpu().numpy()
+
     # ---- batched MMP-DF ------------------------------------------------------------------------------
     def mmpdf_launch(self, sig: torch.Tensor, max_sparsity, connections, branches, dissimilarity,
                      want_coef=True, out=None):

@@ -96,6 +96,21 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
                     double* d_node_coef, double* d_rec_mse, int32_t* d_rec_leaf,
                     int32_t* d_rec_sel, int32_t* d_stats, void* stream);
 
+/* Batched plain convolutional matching pursuit.  Replaces CSCDictionary.mp / mpFromDict /
+ * mpSparVarFromDict (src/csc/dictionary.py:764-921): per iteration, correlations of the residual
+ * (fp32 MFMA + fp64 re-score as in csc_mmpdf_batch), signed arg-max, activation_mask[idx] += <atom, r>,
+ * residual = signal - conv(mask * mask) -- the reference multiplies the mask by itself (:803), kept.
+ * One node per iteration (NN = iterations, node i = state after iteration i + 1):
+ *   d_node_pos / d_node_atom [S][iterations]   activation selected at that iteration
+ *   d_node_mse  [S][iterations]                mean((signal - approx)^2) after it
+ *   d_node_mask [S][iterations][iterations]    mask value per support slot after it (slot q = q-th
+ *               selection; a re-selected activation accumulates in its first slot, the later slot is 0)
+ *   workspace: csc_mmpdf_workspace_bytes(S, N, iterations, 1, 1) bytes. */
+int csc_mp_batch(const float* d_bank32t, const double* d_bank64, int K, int L, const double* d_signals,
+                 int S, int N, int iterations, void* d_workspace, size_t workspace_bytes,
+                 int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse, double* d_node_mask,
+                 int32_t* d_stats, void* stream);
+
 /* Batched least-squares projection on GIVEN supports (fp64 Gram / Cholesky, one workgroup per
  * problem).  Replaces CSCDictionary.getSignalProjectionFromAtoms (src/csc/dictionary.py:449-473:
  * lsqr(masked_conv_op, signal) then op @ activations) and its callers

@@ -378,6 +378,57 @@ def omp_sparvar(dic, signal_dict, max_sparsity, mode="faithful"):
 
 
 # --------------------------------------------------------------------------------------------
+# plain matching pursuit (reference src/csc/dictionary.py:764-921)
+# --------------------------------------------------------------------------------------------
+def mp_steps(dic, signal, sparsity, mode="faithful"):
+    """Yields per iteration (mask {flat idx: value}, approx).  The reference accumulates
+    activation_mask[idx] += corr[idx] and rebuilds approx = masked_conv_op @ activation_mask, i.e.
+    conv(mask * mask): the mask multiplies itself (dictionary.py:796-804)."""
+    signal = np.asarray(signal, dtype=np.float64)
+    N = len(signal)
+    mask, residual = {}, signal
+    for _ in range(sparsity):
+        c = dic.correlations(residual, mode)
+        flat = int(c.argmax())
+        mask[flat] = mask.get(flat, 0.0) + float(c.flat[flat])
+        approx = np.zeros(N)
+        for i, v in mask.items():
+            pos, k = divmod(i, dic.K)
+            approx += v * v * dic.place(k, pos, N)
+        residual = signal - approx
+        yield dict(mask), approx
+
+
+def _mp_atoms_sorted(dic, mask):
+    """np.where order (ascending flat index), then argsort()[::-1] on the mask values
+    (dictionary.py:808-823)."""
+    flat = np.array(sorted(i for i, v in mask.items() if v != 0), dtype=np.int64)
+    vals = np.array([mask[int(i)] for i in flat])
+    order = np.argsort(vals)[::-1]
+    return [dic.atom_info(*divmod(int(i), dic.K)) for i in flat[order]]
+
+
+def mp_from_dict(dic, signal_dict, mode="faithful"):
+    """dictionary.py:827-845."""
+    signal = np.asarray(signal_dict["signal"], dtype=np.float64)
+    for mask, approx in mp_steps(dic, signal, len(signal_dict["atoms"]), mode):
+        pass
+    infos = _mp_atoms_sorted(dic, mask)
+    return {"id": signal_dict["id"], "mse": float(np.mean((signal - approx) ** 2)), "sparsity": len(infos),
+            "approx": approx.tolist(), "atoms": infos}
+
+
+def mp_sparvar(dic, signal_dict, max_sparsity, mode="faithful"):
+    """dictionary.py:847-921."""
+    signal = np.asarray(signal_dict["signal"], dtype=np.float64)
+    out, t0 = [], time.time()
+    for mask, approx in mp_steps(dic, signal, max_sparsity, mode):
+        out.append({"mse": float(np.mean((signal - approx) ** 2)), "atoms": _mp_atoms_sorted(dic, mask),
+                    "delay": time.time() - t0})
+    return {"id": signal_dict["id"], "snr": signal_dict["snr"], "results": out}
+
+
+# --------------------------------------------------------------------------------------------
 # synthetic constrained signals (reference src/csc/dictionary.py:271-365) -- benchmark input
 # --------------------------------------------------------------------------------------------
 def constrained_signal(dic, N, sparsity, snr, pos_err, corr_err):

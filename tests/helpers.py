@@ -54,6 +54,26 @@ class OracleBank:
                     r.rec_sel[s, k - 1, e] = (p, a)
         return r
 
+    def mp_batch(self, signals, iterations):
+        signals = np.atleast_2d(np.asarray(signals, dtype=np.float64))
+        S, I = len(signals), iterations
+        pos, atom = np.zeros((S, I), np.int32), np.zeros((S, I), np.int32)
+        mse, mask = np.zeros((S, I)), np.zeros((S, I, I))
+        for s in range(S):
+            order, prev = [], {}
+            for it, (m, approx) in enumerate(O.mp_steps(self.od, signals[s], I, "direct")):
+                new = [f for f in m if m[f] != prev.get(f)][0]          # the activation touched this iteration
+                order.append(new)
+                prev = dict(m)
+                pos[s, it], atom[s, it] = divmod(new, self.od.K)
+                mse[s, it] = np.mean((signals[s] - approx) ** 2)
+                seen = set()
+                for q, f in enumerate(order):
+                    if f not in seen:
+                        mask[s, it, q] = m[f]
+                        seen.add(f)
+        return pos, atom, mse, mask
+
     def project_batch(self, signals, supports, sig_index=None, want_approx=False):
         signals = np.atleast_2d(np.asarray(signals, dtype=np.float64))
         N = signals.shape[1]

@@ -72,6 +72,16 @@ def test_pipelines_json(dic, golden_signals, tmp_path):
     H.test_other_pipelines_json(dic, golden_signals, tmp_path)
 
 
+def test_matching_pursuit(dic, golden_signals, tmp_path):
+    H.test_matching_pursuit(dic, golden_signals)
+    H.test_mp_pipelines_json(dic, golden_signals, tmp_path)
+    ref = load_json("mp.json")                       # all golden MP runs, batched in one call per depth
+    sigs, atoms = golden_signals["signals"], golden_signals["atoms"]
+    for r in ref["mp"]:
+        got = dic.mpFromDict({"id": r["id"], "signal": sigs[r["id"]].tolist(), "atoms": atoms[r["id"]]})
+        assert got["atoms"] == r["atoms"] and abs(got["mse"] - r["mse"]) <= 1e-9 * r["mse"]
+
+
 def test_compute_correlations_api(dic, golden_signals):
     z = np.load(os.path.join(H.ROOT, "tests", "golden", "rootcorr.npz"))
     sig = golden_signals["signals"][int(z["sig_idx"][0])]

@@ -140,6 +140,42 @@ def test_mmptree_view(dic, golden_signals):
     assert len(csc_amd.MMPTree.shrinkMMPTreeDict(dict(td), 4)) == 4
 
 
+def test_matching_pursuit(dic, golden_signals):
+    ref = load_json("mp.json")
+    sigs, atoms = golden_signals["signals"], golden_signals["atoms"]
+    for r in ref["mp"][::4]:
+        i = r["id"]
+        got = dic.mpFromDict({"id": i, "signal": sigs[i].tolist(), "atoms": atoms[i]})
+        assert list(got) == ["id", "mse", "sparsity", "approx", "atoms"]
+        assert got["atoms"] == r["atoms"] and got["sparsity"] == r["sparsity"] and _close(got["mse"], r["mse"])
+        assert np.allclose(got["approx"][:6], r["approx_head"], rtol=1e-9, atol=1e-15)
+        approx, infos = dic.mp(sigs[i], len(atoms[i]))
+        assert infos == r["atoms"]
+    for r in ref["mp_sparvar"]:       # 8 iterations: some runs re-select an activation (its mask accumulates)
+        i = r["id"]
+        got = dic.mpSparVarFromDict({"id": i, "snr": r["snr"], "signal": sigs[i].tolist()}, 8)
+        assert (got["id"], got["snr"]) == (r["id"], r["snr"]) and len(got["results"]) == 8
+        for g, x in zip(got["results"], r["results"]):
+            assert list(g) == ["mse", "atoms", "delay"]
+            assert g["atoms"] == x["atoms"] and _close(g["mse"], x["mse"])
+
+
+def test_mp_pipelines_json(dic, golden_signals, tmp_path):
+    ref = load_json("mp.json")
+    idx = [r["id"] for r in ref["mp"][:3]]
+    src = str(tmp_path / "db.json")
+    _write_db(src, golden_signals, idx)
+    dic.mpPipelineFromDB(src, str(tmp_path / "m.json"), 1)
+    out = json.load(open(tmp_path / "m.json"))
+    assert list(out) == ["source", "date", "algorithm", "batchSize", "snrLevels", "signalLength", "sparsityLevels",
+                         "dictionary", "mp"] and out["algorithm"] == "Convolutional MP"
+    for got, r in zip(out["mp"], ref["mp"][:3]):
+        assert got["atoms"] == r["atoms"] and _close(got["mse"], r["mse"])
+    dic.mpSparVarPipelineFromDB(src, str(tmp_path / "ms.json"), 1, 3)
+    out = json.load(open(tmp_path / "ms.json"))
+    assert list(out)[5] == "maxSparsityLevel" and len(out["mp"][0]["results"]) == 3
+
+
 def _write_db(path, golden_signals, idx):
     sigs = [{"id": int(i), "snr": int(golden_signals["snr"][i]), "sparsity": int(golden_signals["sparsity"][i]),
              "signal": golden_signals["signals"][i].tolist(), "atoms": golden_signals["atoms"][i]} for i in idx]

@@ -169,3 +169,19 @@ def test_misc_drivers(golden_signals, oracle_dict):
         for p, v in r["mmp-tree"].items():
             assert td[p]["atoms"] == v["atoms"]
             assert abs(td[p]["mse"] - v["mse"]) <= 1e-9 * v["mse"]
+
+
+def test_matching_pursuit(golden_signals, oracle_dict):
+    ref = load_json("mp.json")
+    sigs, atoms = golden_signals["signals"], golden_signals["atoms"]
+    for n, r in enumerate(ref["mp"]):
+        i = r["id"]
+        mode = "faithful" if n % 7 == 0 else "direct"
+        got = O.mp_from_dict(oracle_dict, {"id": i, "signal": sigs[i], "atoms": atoms[i]}, mode)
+        assert got["atoms"] == r["atoms"] and got["sparsity"] == r["sparsity"]
+        assert abs(got["mse"] - r["mse"]) <= (1e-13 if mode == "faithful" else 1e-9) * r["mse"]
+    for r in ref["mp_sparvar"][:4]:
+        i = r["id"]
+        got = O.mp_sparvar(oracle_dict, {"id": i, "snr": r["snr"], "signal": sigs[i]}, 8, "direct")
+        for g, x in zip(got["results"], r["results"]):
+            assert g["atoms"] == x["atoms"] and abs(g["mse"] - x["mse"]) <= 1e-9 * x["mse"]
