@@ -5,13 +5,13 @@ dictionary classes (``CSC*`` in its sources, ``ZS*`` in its README and wheel).  
 ``csrc/libcsc_hip.so`` (C ABI in ``include/csc_hip.h``); there is no CPU solver here.
 """
 from .atoms import CSCAtom, ZSAtom, der_zs_formula
-from .dictionary import CSCDictionary, ZSDictionary
+from .dictionary import CSCDictionary, ZSDictionary, SparVarBatch
 from .mmp import MMPNode, MMPTree
 from .main import conv_multipath_matching_pursuit
 from .workbench import CSCWorkbench
 from .utils import computeMaxTruePositives, getMatchedAtoms, handle_non_serializable, get_today_date_str
 
-__all__ = ["CSCAtom", "ZSAtom", "CSCDictionary", "ZSDictionary", "MMPNode", "MMPTree", "CSCWorkbench",
+__all__ = ["CSCAtom", "ZSAtom", "CSCDictionary", "ZSDictionary", "SparVarBatch", "MMPNode", "MMPTree", "CSCWorkbench",
            "conv_multipath_matching_pursuit", "computeMaxTruePositives", "getMatchedAtoms",
            "handle_non_serializable", "get_today_date_str", "der_zs_formula"]
 __version__ = "0.1.0"

@@ -577,6 +577,18 @@ class CSCDictionary:
         res, dt = self._batch(signal_dict["signal"], max_sparsity, connections_level, nb_branches, dissimilarity)
         return {"id": signal_dict["id"], "snr": signal_dict["snr"], "results": self._sparvar_records(res, 0, dt)}
 
+    def mmpdfSparVarBatch(self, signals, connections_level: int = 3, dissimilarity: float = 0.8,
+                          nb_branches: int = 10, max_sparsity: int = 10, sharded: bool = False):
+        """Array-in / array-out twin of mmpdfSparVarPipelineFromDB for batches that do not fit JSON
+        (BASELINE config 5: 10^6 signals).  ``signals`` is an [S, N] float array (or anything
+        np.asarray accepts); returns a ``SparVarBatch`` (None on ranks != 0 when ``sharded`` under
+        torch.distributed).  Same numbers as the per-signal records of mmpdfSparVarFromDict
+        (reference :1047-1071)."""
+        res, dt = self._batch(signals, max_sparsity, connections_level, nb_branches, dissimilarity, sharded=sharded)
+        if res is None:
+            return None
+        return SparVarBatch(self, res, dt)
+
     # ------------------------------------------------------------------------------------------
     # pipelines: JSON DB -> one batched device call -> JSON (reference :683-756, 1073-1152)
     # ------------------------------------------------------------------------------------------
@@ -693,6 +705,39 @@ class CSCDictionary:
         self._dump(results, output_filename)
         if verbose:
             print(f"MMP-DF SparVar Pipeline results saved in {output_filename}")
+
+
+class SparVarBatch:
+    """Per-sparsity winners of a whole batch as arrays (what one device call + one gather returns):
+    ``mse`` [S, K]; ``leaf`` [S, K] index of the winning leaf ('<=' rule, reference mmp.py:586);
+    ``pos`` / ``atom`` [S, K, K] root -> leaf selections of the sparsity-k winner, -1 padded."""
+
+    def __init__(self, dictionary, res, seconds_per_signal):
+        self.dictionary, self.connections, self.max_sparsity = dictionary, res.connections, res.max_sparsity
+        self.mse = res.rec_mse
+        self.leaf = res.rec_leaf[:, :, 0]
+        self.pos, self.atom = res.rec_sel[..., 0], res.rec_sel[..., 1]
+        self.seconds_per_signal = seconds_per_signal
+        self._res = res
+
+    def __len__(self):
+        return len(self.mse)
+
+    def path(self, s, k) -> str:
+        return self._res.path_str(k, int(self.leaf[s, k - 1]))
+
+    def record(self, s, signal_id=None, snr=None) -> dict:
+        """The reference's sparVar dict of signal ``s`` ({'id','snr','results':[...]})."""
+        return {"id": s if signal_id is None else signal_id, "snr": snr,
+                "results": self.dictionary._sparvar_records(self._res, s, self.seconds_per_signal)}
+
+    def save_npz(self, path, **extra):
+        """Compact binary form (~(16 + 8K) K bytes per signal instead of ~1.5 KB of JSON)."""
+        d = self.dictionary
+        np.savez_compressed(path, mse=self.mse, leaf=self.leaf, pos=self.pos, atom=self.atom,
+                            connections=self.connections, atom_b=np.array([a.b for a in d.atoms]),
+                            atom_y=np.array([a.y for a in d.atoms]), atom_sigma=np.array([a.sigma for a in d.atoms]),
+                            **extra)
 
 
 ZSDictionary = CSCDictionary   # README / wheel spelling of the same class

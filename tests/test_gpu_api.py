@@ -82,6 +82,10 @@ def test_matching_pursuit(dic, golden_signals, tmp_path):
         assert got["atoms"] == r["atoms"] and abs(got["mse"] - r["mse"]) <= 1e-9 * r["mse"]
 
 
+def test_sparvar_batch_arrays(dic, golden_signals, tmp_path):
+    H.test_sparvar_batch_arrays(dic, golden_signals, tmp_path)
+
+
 def test_compute_correlations_api(dic, golden_signals):
     z = np.load(os.path.join(H.ROOT, "tests", "golden", "rootcorr.npz"))
     sig = golden_signals["signals"][int(z["sig_idx"][0])]

@@ -140,6 +140,19 @@ def test_mmptree_view(dic, golden_signals):
     assert len(csc_amd.MMPTree.shrinkMMPTreeDict(dict(td), 4)) == 4
 
 
+def test_sparvar_batch_arrays(dic, golden_signals, tmp_path):
+    sub = golden_signals["signals"][::4][:5]
+    ref = load_json("sparvar.json")["c3_B3_K5_thr0.8"]
+    b = dic.mmpdfSparVarBatch(sub, 3, 0.8, 3, 5)
+    assert len(b) == 5 and b.mse.shape == (5, 5) and b.pos.shape == (5, 5, 5)
+    for s in range(5):
+        check_sparvar(b.record(s, ref[s]["id"], ref[s]["snr"]), ref[s])
+        assert (b.pos[s, 1, 2:] == -1).all() and b.path(s, 1) in ("1", "2", "3")
+    b.save_npz(str(tmp_path / "r.npz"), ids=np.arange(5))
+    z = np.load(tmp_path / "r.npz")
+    assert np.array_equal(z["mse"], b.mse) and len(z["atom_b"]) == 143 and int(z["connections"]) == 3
+
+
 def test_matching_pursuit(dic, golden_signals):
     ref = load_json("mp.json")
     sigs, atoms = golden_signals["signals"], golden_signals["atoms"]
