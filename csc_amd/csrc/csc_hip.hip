@@ -894,6 +894,19 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
                     if (permv[ni] < 0) acc[mi][ni][rg] = -INFINITY;
         }
 
+#ifdef CSC_PHASE_PROF
+    if (a.stagger_ticks == -7) {                  // development aid: GEMM only (CSC_STAGGER_US=-7 hack off by default)
+        float lm = -INFINITY;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) lm = fmaxf(lm, acc[mi][ni][rg]);
+        if (lm == 12345.f) a.node_mse[0] = lm;
+        return;
+    }
+#endif
     // ---- children, one selection round per sibling -------------------------------------------------
     bool lane_supp = false;                       // this lane holds a suppressed (value 0) entry
     for (int t = 0; t < nch; ++t) {
@@ -1319,9 +1332,13 @@ static size_t level_lds_bytes(int N, int Lp) {
 
 static int stagger_ticks() {
     static int v = -1;
-    if (v < 0) {
+    if (v == -1) {
         const char* e = getenv("CSC_STAGGER_US");
         v = e ? atoi(e) * 100 : 0;                                    // wall_clock64 runs at 100 MHz
+#ifdef CSC_PHASE_PROF
+        if (getenv("CSC_GEMM_ONLY")) v = -7;
+        else
+#endif
         if (v < 0 || v > 100000) v = 0;
     }
     return v;

@@ -96,7 +96,9 @@ class OracleDictionary:
         """(P, K) valid cross-correlations (reference src/csc/dictionary.py:395-407)."""
         signal = np.asarray(signal, dtype=np.float64)
         if mode == "faithful":
-            rev = self.bank[:, ::-1]
+            # the reference rebuilds the reversed atom matrix from the atom objects on every call
+            # (dictionary.py:404); kept, because this mode is also the timed CPU baseline
+            rev = np.array([row[::-1] for row in self.bank])
             stacked = np.stack([signal] * self.K, axis=1)
             return oaconvolve(stacked, rev.T, mode="valid", axes=0)
         win = np.lib.stride_tricks.sliding_window_view(signal, self.L)   # (P, L)
@@ -105,7 +107,8 @@ class OracleDictionary:
     def convolutions(self, activations):
         """(N,) synthesis (reference src/csc/dictionary.py:380-393)."""
         act = np.reshape(activations, (-1, self.K))
-        return oaconvolve(act, self.bank.T, mode="full", axes=0).sum(axis=1)
+        atoms = np.array([row for row in self.bank])          # per-call rebuild, as dictionary.py:390
+        return oaconvolve(act, atoms.T, mode="full", axes=0).sum(axis=1)
 
     def masked_conv_operator(self, mask):
         """conv o diag(mask) as a LinearOperator (reference src/csc/dictionary.py:409-425)."""

@@ -1,16 +1,20 @@
-"""Development aid: MFMA rate of the correlation GEMM alone (csc_correlate), no selection / LS."""
-import sys, numpy as np, torch
+"""Development aid (prof build, CSC_GEMM_ONLY=1): level-kernel launch times with the children skipped."""
+import sys, torch
 sys.path.insert(0, ".")
 import bench
+from csc_amd import _lib
 dic = bench.canonical_dictionary()
 bank = dic.device_bank()
-S = 9600
-sig = torch.randn(S, 738, dtype=torch.float64, device="cuda")
-out = bank.correlate(sig)
+d = torch.from_numpy(bench.make_signals(dic, 0)).cuda()
+out = bank.mmpdf_launch(d, 5, 3, 3, 0.8, want_coef=False)
 torch.cuda.synchronize()
-for _ in range(3):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); out = bank.correlate(sig); e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1)
-    issued = S * 101 * 4 * 32 * 2048 / (ms * 1e-3) / 1e12
-    print(f"{ms:.3f} ms  {S / ms * 1e3:.0f} nodes/s  dense {S * 2 * 247 * 143 * 492 / ms / 1e9:.1f} TF  issued {issued:.1f} TF ({issued / 157.3:.2f} of peak)")
+t = _lib.LevelTimer(64)
+with t:
+    for _ in range(3):
+        bank.mmpdf_launch(d, 5, 3, 3, 0.8, want_coef=False, out=out)
+    torch.cuda.synchronize()
+sp = t.read()
+for lv in range(5):
+    ms = sum(m for l, m in sp if l == lv) / 3
+    n = 3200 * (1 if lv == 0 else 3)
+    print(f"level {lv}: {ms:.3f} ms  {ms * 1e-3 * 2.4e9 * 256 / n:.0f} clk/node/CU  MFMA-issue {103424 / (ms * 1e-3 * 2.4e9 * 256 / n):.2f}")
