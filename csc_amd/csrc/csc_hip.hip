@@ -1249,6 +1249,72 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled_kernel(const LevelArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
+// batched atom matching (API parity: utils.computeMaxTruePositives)
+// ------------------------------------------------------------------------------------------------
+// One wave per problem.  cost[i][j] = 0 where |pos_i - pos_j| <= pos_thr and |<a_i @ pos_i, a_j @ pos_j>|
+// >= corr_thr (src/csc/utils.py:34-58); the optimum of linear_sum_assignment on that 0/1 cost is the size
+// of a maximum bipartite matching of the zero entries, found here with augmenting paths on bit masks.
+#define MATCH_MAX 16
+__global__ __launch_bounds__(64) void match_kernel(const double* __restrict__ bank64, int K, int L,
+                                                   const int32_t* __restrict__ truth, int kt,
+                                                   const int32_t* __restrict__ approx, int ka,
+                                                   double pos_thr, double corr_thr, int32_t* __restrict__ tp) {
+    __shared__ uint32_t adj[MATCH_MAX];            // adj[i] bit j: true atom i may match approx atom j
+    const int lane = threadIdx.x;
+    const size_t m = blockIdx.x;
+    const int32_t* T = truth + m * kt * 2;
+    const int32_t* A = approx + m * ka * 2;
+    if (lane < MATCH_MAX) adj[lane] = 0;
+    __syncthreads();
+    for (int i = 0; i < kt; ++i) {
+        const int pi = T[2 * i], ki = T[2 * i + 1];
+        if (pi < 0 || ki < 0 || ki >= K) continue;                   // padding
+        for (int j = 0; j < ka; ++j) {
+            const int pj = A[2 * j], kj = A[2 * j + 1];
+            if (pj < 0 || kj < 0 || kj >= K) continue;
+            if (fabs((double)(pi - pj)) > pos_thr) continue;           // wave-uniform
+            const int dp = pi - pj;                                   // a_j index = l + dp
+            double v = dot_range<64>(bank64 + (size_t)ki * L, bank64 + (size_t)kj * L + dp, max(0, -dp),
+                                     min(L, L - dp), lane);
+            v = wave_sum(v);
+            if (lane == 63 && fabs(v) >= corr_thr) adj[i] |= 1u << j;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int owner[MATCH_MAX];                                         // true atom matched to approx atom j
+        for (int j = 0; j < MATCH_MAX; ++j) owner[j] = -1;
+        int matched = 0;
+        for (int i0 = 0; i0 < kt; ++i0) {
+            // iterative augmenting-path search from i0 (depth <= kt)
+            int stack_i[MATCH_MAX], stack_j[MATCH_MAX], prev_owner_j[MATCH_MAX];
+            uint32_t visited = 0;
+            int depth = 0;
+            stack_i[0] = i0; stack_j[0] = -1;
+            bool found = false;
+            while (depth >= 0 && !found) {
+                const int i = stack_i[depth];
+                int j = stack_j[depth] + 1;
+                for (; j < ka; ++j) if (((adj[i] >> j) & 1u) && !((visited >> j) & 1u)) break;
+                if (j >= ka) { --depth; continue; }
+                stack_j[depth] = j;
+                visited |= 1u << j;
+                if (owner[j] < 0) { found = true; break; }
+                stack_i[depth + 1] = owner[j];
+                stack_j[depth + 1] = -1;
+                ++depth;
+            }
+            if (found) {
+                for (int q = depth; q >= 0; --q) owner[stack_j[q]] = stack_i[q];
+                ++matched;
+            }
+            (void)prev_owner_j;
+        }
+        tp[m] = matched;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // per-sparsity winners (src/csc/mmp.py:577-606 '<=' = last minimum; :464 np.argmin = first)
 // ------------------------------------------------------------------------------------------------
 __global__ void reduce_kernel(int S, int Kmax, int NN, TreeShape ts, const int32_t* __restrict__ node_pos,
@@ -1536,6 +1602,20 @@ int csc_mp_batch(const float* d_bank32t, const double* d_bank64, int K, int L, c
     return run_levels(1, d_bank32t, d_bank64, nullptr, K, L, d_signals, S, N, iterations, 1, 1, d_workspace,
                       workspace_bytes, d_node_pos, d_node_atom, d_node_mse, d_node_mask, nullptr, nullptr,
                       nullptr, d_stats, stream);
+}
+
+int csc_match_batch(const double* d_bank64, int K, int L, const int32_t* d_true, int kt,
+                    const int32_t* d_approx, int ka, int M, double pos_err_threshold,
+                    double corr_err_threshold, int32_t* d_tp, void* stream) {
+    if (!d_bank64 || !d_true || !d_approx || !d_tp || K <= 0 || L <= 0 || M < 0)
+        FAIL(-1, "csc_match_batch: bad arguments");
+    if (kt < 1 || kt > MATCH_MAX || ka < 1 || ka > MATCH_MAX)
+        FAIL(-2, "csc_match_batch: %d x %d atoms outside [1, %d]", kt, ka, MATCH_MAX);
+    if (M == 0) return 0;
+    clear_stale_error();
+    hipLaunchKernelGGL(match_kernel, dim3((unsigned)M), dim3(64), 0, (hipStream_t)stream, d_bank64, K, L, d_true, kt,
+                       d_approx, ka, pos_err_threshold, corr_err_threshold, d_tp);
+    return launch_status("match_kernel");
 }
 
 int csc_project_batch(const double* d_bank64, int K, int L, const double* d_signals, int S, int N,

@@ -214,6 +214,26 @@ class CSCDictionary:
                                                         sig_index=np.zeros(len(atoms_lists), np.int32))
         return [float(m) for m in mse]
 
+    def maxTruePositivesBatch(self, true_atoms_lists: List[List[dict]], approx_atoms_lists: List[List[dict]],
+                              pos_err_threshold: float, corr_err_threshold: float) -> np.ndarray:
+        """Max number of true positives of every (truth, recovered) pair -- the first return value of
+        utils.computeMaxTruePositives (reference utils.py:23-69) -- for a whole result set in one
+        device call."""
+        if len(true_atoms_lists) != len(approx_atoms_lists):
+            raise ValueError("one recovered list per truth list")
+        if len(true_atoms_lists) == 0:
+            return np.zeros(0, np.int32)
+
+        def pack(lists):
+            k = max(1, max(len(x) for x in lists))
+            arr = np.full((len(lists), k, 2), -1, dtype=np.int32)
+            for m, infos in enumerate(lists):
+                for q, info in enumerate(infos):
+                    arr[m, q] = (int(info["x"]), self._atom_index(info))
+            return arr
+        return self.device_bank().match_batch(pack(true_atoms_lists), pack(approx_atoms_lists),
+                                              pos_err_threshold, corr_err_threshold)
+
     def getAtomFromActivationIdx(self, activation_idx: int) -> Tuple[CSCAtom, int]:
         return self.atoms[activation_idx % len(self.atoms)], activation_idx // len(self.atoms)
 
@@ -730,6 +750,20 @@ class SparVarBatch:
         """The reference's sparVar dict of signal ``s`` ({'id','snr','results':[...]})."""
         return {"id": s if signal_id is None else signal_id, "snr": snr,
                 "results": self.dictionary._sparvar_records(self._res, s, self.seconds_per_signal)}
+
+    def true_positives(self, true_atoms_lists, pos_err_threshold, corr_err_threshold) -> np.ndarray:
+        """[S, K] max true positives of the sparsity-k winner of every signal against its ground-truth
+        atoms (what the workbench's sparVar metrics start from), one device call."""
+        d, S, K = self.dictionary, len(self), self.max_sparsity
+        kt = max(1, max(len(t) for t in true_atoms_lists))
+        truth = np.full((S, kt, 2), -1, np.int32)
+        for s, infos in enumerate(true_atoms_lists):
+            for q, info in enumerate(infos):
+                truth[s, q] = (int(info["x"]), d._atom_index(info))
+        approx = np.stack([self.pos, self.atom], axis=-1).astype(np.int32)          # [S, K, K, 2]
+        tp = d.device_bank().match_batch(np.repeat(truth, K, axis=0), approx.reshape(S * K, K, 2),
+                                         pos_err_threshold, corr_err_threshold)
+        return tp.reshape(S, K)
 
     def save_npz(self, path, **extra):
         """Compact binary form (~(16 + 8K) K bytes per signal instead of ~1.5 KB of JSON)."""

@@ -195,6 +195,23 @@ class DeviceBank:
         return (coef.cpu().numpy(), mse.cpu().numpy(), approx.cpu().numpy() if want_approx else None,
                 int(stats[1].item()))
 
+    # ---- batched atom matching (utils.computeMaxTruePositives) -------------------------------------------
+    def match_batch(self, truth, approx, pos_err_threshold, corr_err_threshold) -> np.ndarray:
+        """truth [M, kt, 2], approx [M, ka, 2] int32 (pos, atom), -1 padded -> true-positive counts [M]."""
+        t = np.ascontiguousarray(truth, dtype=np.int32)
+        a = np.ascontiguousarray(approx, dtype=np.int32)
+        M = t.shape[0]
+        if a.shape[0] != M or t.ndim != 3 or a.ndim != 3 or t.shape[2] != 2 or a.shape[2] != 2:
+            raise ValueError("truth / approx must be [M, k, 2] with the same M")
+        with torch.cuda.device(self.device):
+            d_t, d_a = torch.from_numpy(t).to(self.device), torch.from_numpy(a).to(self.device)
+            tp = torch.zeros(M, dtype=torch.int32, device=self.device)
+            _lib.check(self.lib.csc_match_batch(_ptr(self.bank64), self.K, self.L, _ptr(d_t), t.shape[1], _ptr(d_a),
+                                                a.shape[1], M, float(pos_err_threshold), float(corr_err_threshold),
+                                                _ptr(tp), _stream(self.device)), "csc_match_batch")
+            torch.cuda.synchronize(self.device)
+        return tp.cpu().numpy()
+
     # ---- batched matching pursuit (mp / mpFromDict / mpSparVarFromDict) -----------------------------------
     def mp_batch(self, signals, iterations):
         """signals [S, N] -> host (pos [S, I], atom [S, I], mse [S, I], mask [S, I, I]); row i = state after

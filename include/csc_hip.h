@@ -129,6 +129,18 @@ int csc_project_batch(const double* d_bank64, int K, int L, const double* d_sign
                       const int32_t* d_sig_index, const int32_t* d_support, int M, int kmax,
                       double* d_coef, double* d_mse, double* d_approx, int32_t* d_stats, void* stream);
 
+/* Batched atom matching.  Replaces utils.computeMaxTruePositives (src/csc/utils.py:23-69) for M
+ * (truth, recovered) pairs at once: the maximum number of true positives = size of a maximum matching
+ * between true and recovered atoms whose positions differ by <= pos_err_threshold AND whose placed
+ * atoms have |inner product| >= corr_err_threshold (the optimum of the reference's Hungarian
+ * assignment on the same 0/1 cost).  Positions may be any integers (the inner product of
+ * non-overlapping placements is 0).
+ *   d_true   [M][kt][2] int32 (pos, atom), pad with -1      d_approx [M][ka][2] int32, pad with -1
+ *   d_tp     [M] int32                                       kt, ka <= 16 */
+int csc_match_batch(const double* d_bank64, int K, int L, const int32_t* d_true, int kt,
+                    const int32_t* d_approx, int ka, int M, double pos_err_threshold,
+                    double corr_err_threshold, int32_t* d_tp, void* stream);
+
 /* Optional per-launch HIP-event timer.  No counterpart in the reference (its time_decorator,
  * src/csc/dictionary.py:25-45, logs host wall-clock per method); bench.py uses it to measure the
  * level kernel's launch durations live, on the stream the kernel runs on.  While a timer is

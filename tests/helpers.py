@@ -74,6 +74,25 @@ class OracleBank:
                         seen.add(f)
         return pos, atom, mse, mask
 
+    def match_batch(self, truth, approx, pos_thr, corr_thr):
+        from scipy import optimize
+        out = np.zeros(len(truth), np.int32)
+        N = 4 * self.L
+        for m in range(len(truth)):
+            T = [(int(p), int(k)) for p, k in truth[m] if p >= 0]
+            A = [(int(p), int(k)) for p, k in approx[m] if p >= 0]
+            if not T or not A:
+                continue
+            cost = np.ones((len(T), len(A)))
+            for i, (pi, ki) in enumerate(T):
+                for j, (pj, kj) in enumerate(A):
+                    c = abs(np.dot(self.od.place(ki, pi, N), self.od.place(kj, pj, N)))
+                    if abs(pi - pj) <= pos_thr and c >= corr_thr:
+                        cost[i, j] = 0
+            r, c = optimize.linear_sum_assignment(cost)
+            out[m] = int(np.sum(cost[r, c] == 0))
+        return out
+
     def project_batch(self, signals, supports, sig_index=None, want_approx=False):
         signals = np.atleast_2d(np.asarray(signals, dtype=np.float64))
         N = signals.shape[1]

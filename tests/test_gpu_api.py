@@ -86,6 +86,18 @@ def test_sparvar_batch_arrays(dic, golden_signals, tmp_path):
     H.test_sparvar_batch_arrays(dic, golden_signals, tmp_path)
 
 
+def test_true_positive_counts(dic, golden_signals):
+    H.test_true_positive_counts(dic, golden_signals)
+    # adversarial matching instance: augmenting paths are needed (greedy would find 2 of 3)
+    bank = dic.device_bank()
+    truth = np.array([[[10, 5], [12, 5], [14, 5]]], np.int32)
+    approx = np.array([[[11, 5], [13, 5], [30, 5]]], np.int32)
+    assert bank.match_batch(truth, approx, 1, 0.5).tolist() == [2]
+    approx = np.array([[[11, 5], [13, 5], [15, 5]]], np.int32)
+    assert bank.match_batch(truth, approx, 1, 0.5).tolist() == [3]
+    assert bank.match_batch(truth, approx, 1, 1.5).tolist() == [0]
+
+
 def test_compute_correlations_api(dic, golden_signals):
     z = np.load(os.path.join(H.ROOT, "tests", "golden", "rootcorr.npz"))
     sig = golden_signals["signals"][int(z["sig_idx"][0])]

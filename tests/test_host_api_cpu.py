@@ -153,6 +153,32 @@ def test_sparvar_batch_arrays(dic, golden_signals, tmp_path):
     assert np.array_equal(z["mse"], b.mse) and len(z["atom_b"]) == 143 and int(z["connections"]) == 3
 
 
+def test_true_positive_counts(dic, golden_signals):
+    """maxTruePositivesBatch / SparVarBatch.true_positives vs the reference's computeMaxTruePositives"""
+    import csc_amd
+    ref = load_json("metrics.json")
+    truth = golden_signals["atoms"][::4]
+    sv = load_json("sparvar.json")["c3_B3_K5_thr0.8"]
+    for case in ref["cases"]:
+        pt, ct = case["pos_err_threshold"], case["corr_err_threshold"]
+        t_lists = [t for t in truth for _ in range(5)]
+        a_lists = [r["atoms"] for rec in sv for r in rec["results"]]
+        got = dic.maxTruePositivesBatch(t_lists, a_lists, pt, ct).reshape(16, 5)
+        assert got.tolist() == case["tp"], (pt, ct)
+    # the host-side single-pair function agrees too (scipy assignment, as the reference)
+    case = ref["cases"][0]
+    for s in (0, 7):
+        for k in range(5):
+            tp, _ = csc_amd.computeMaxTruePositives(dic, 738, truth[s], sv[s]["results"][k]["atoms"], 10, 0.75)
+            assert tp == case["tp"][s][k]
+    b = dic.mmpdfSparVarBatch(golden_signals["signals"][::4], 3, 0.8, 3, 5)
+    got = b.true_positives(truth, 10, 0.75)
+    want = np.array(case["tp"])
+    same_path = np.array([[b.path(s, k + 1) == sv[s]["results"][k]["path"] for k in range(5)] for s in range(16)])
+    assert (got == want)[same_path].all() and same_path.mean() > 0.9
+    assert dic.maxTruePositivesBatch([], [], 1, 0.5).shape == (0,)
+
+
 def test_matching_pursuit(dic, golden_signals):
     ref = load_json("mp.json")
     sigs, atoms = golden_signals["signals"], golden_signals["atoms"]
