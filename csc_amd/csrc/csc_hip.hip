@@ -42,8 +42,10 @@
 #define KMAX CSC_MAX_SPARSITY
 #define TRI(n) ((n) * ((n) + 1) / 2)
 #define DELTA_REL 6.103515625e-05f      // 2^-14: fp32 candidate band, in units of ||residual||
+#define GRAM_W (2 * CSC_TILE_ROWS)     // shifts per (atom, column) row of the cross-correlation table
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte access
 
 // Development aid (make prof): per-phase shader-clock totals of mmp_level_kernel, summed over workgroups.
 #ifdef CSC_PHASE_PROF
@@ -72,13 +74,16 @@ struct LevelArgs {
     int K, L, Lp, N, P, W;
     int depth;            // level d of the parents expanded by this launch
     int Kmax, connections, NN;
-    int NS;               // doubles per node in the workspace: N residual + TRI(Kmax) Cholesky factor
+    int NS;               // doubles per node in the workspace: N residual + TRI(Kmax) Cholesky factor + Kmax coefficients
     int stagger_ticks;    // > 0: initial phase offset between the two workgroups of a CU (100 MHz ticks)
     int mode;             // 0: orthogonal (OMP / MMP-DF least squares); 1: plain matching pursuit
     const double* resid_in;   // d == 0: signals [S][N]; else [S][F[d]][NS]
     double* resid_out;        // [S][F[d+1]][NS] or nullptr (children are final leaves)
     int32_t* node_pos; int32_t* node_atom; double* node_mse; double* node_coef;
     int32_t* stats;
+    const float* gram;    // atom cross-correlation table [K][144][GRAM_W] f32 or nullptr (always the GEMM)
+    float* c0;            // [S][144][256] f32: correlations of the ORIGINAL signals, written by level 0
+    double* ynorm2;       // [S] squared norm of the original signals, written by level 0
     TreeShape ts;
 };
 
@@ -391,6 +396,38 @@ __global__ __launch_bounds__(WG) void sim_table_kernel(const double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// atom cross-correlation table: X[ks][c][dp + P - 1] = sum_j a_k[j] * a_ks[j + dp], k = atom of bank column c
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void gram_table_kernel(const double* __restrict__ bank64,
+                                                        const int32_t* __restrict__ meta, int K, int L, int P,
+                                                        float* __restrict__ gram) {
+    extern __shared__ double sm[];
+    double* a_sel = sm;            // [L]
+    double* a_k = sm + L;          // [L]
+    const int ksel = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const int k = meta[c];
+    float* row = gram + ((size_t)ksel * CSC_TILE_COLS + c) * GRAM_W;
+    if (k < 0) {                                                     // padding column
+        for (int i = tid; i < GRAM_W; i += WG) row[i] = 0.f;
+        return;
+    }
+    for (int i = tid; i < L; i += WG) {
+        a_sel[i] = bank64[(size_t)ksel * L + i];
+        a_k[i] = bank64[(size_t)k * L + i];
+    }
+    __syncthreads();
+    for (int dpi = tid; dpi < GRAM_W; dpi += WG) {
+        double acc = 0.0;
+        if (dpi < 2 * P - 1) {
+            const int dp = dpi - (P - 1);
+            const int j0 = max(0, -dp), j1 = min(L, L - dp);
+            for (int j = j0; j < j1; ++j) acc = fma(a_k[j], a_sel[j + dp], acc);
+        }
+        row[dpi] = (float)acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // stand-alone batched correlation (API parity: computeCorrelations)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG, 2) void correlate_kernel(const float* __restrict__ bank32t,
@@ -588,7 +625,8 @@ struct NodeLds {
 // residual -> LDS (fp64 + fp32 window copy), ancestors' (pos, atom), parent's coefficients and Cholesky
 // factor.  Returns the fp32 candidate band delta = 2^-14 * ||residual||.  Ends with a barrier.
 __device__ __forceinline__ float node_prologue(const LevelArgs& a, NodeLds* sl, double* r64, float* r32,
-                                               int Npad, int R32, const double* __restrict__ rin, size_t s, int j) {
+                                               int Npad, int R32, const double* __restrict__ rin, size_t s, int j,
+                                               double& rnorm2_out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, d = a.depth;
     double ss = 0.0;
@@ -612,13 +650,14 @@ __device__ __forceinline__ float node_prologue(const LevelArgs& a, NodeLds* sl, 
         const size_t id = s * a.NN + a.ts.off[e] + (j % a.ts.pw[e]);
         sl->sup_pos[tid] = a.node_pos[id];
         sl->sup_atom[tid] = a.node_atom[id];
-        sl->coefpar[tid] = a.node_coef ? a.node_coef[(s * a.NN + a.ts.off[d] + j) * (size_t)a.Kmax + tid] : 0.0;
+        sl->coefpar[tid] = rin[N + TRI(a.Kmax) + tid];               // vs the original signal (mode 1: mask values)
     }
     if (tid >= 64 && tid < 64 + TRI(d)) sl->Lf[tid - 64] = rin[N + tid - 64];
     ss = wave_sum(ss);
     if (lane == 63) sl->wsum[wave] = ss;
     __syncthreads();
     const double rnorm2 = sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3];
+    rnorm2_out = rnorm2;
     return DELTA_REL * (float)sqrt(rnorm2);
 }
 
@@ -714,7 +753,11 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
             a.node_atom[cid] = k_sel;
             a.node_mse[cid] = (sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3]) / (double)N;
         }
-        if (a.node_coef && tid < a.Kmax) a.node_coef[cid * a.Kmax + tid] = tid <= d ? sl->x[tid] : 0.0;
+        if (tid < a.Kmax) {
+            const double cv = tid <= d ? sl->x[tid] : 0.0;
+            if (a.node_coef) a.node_coef[cid * a.Kmax + tid] = cv;
+            if (rout) rout[N + TRI(a.Kmax) + tid] = cv;
+        }
         return;
     }
     // ---- one new Gram column (fp64 dots, one per half-wave) ------------------------------------------
@@ -815,9 +858,11 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
         a.node_atom[cid] = k_sel;
         a.node_mse[cid] = (sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3]) / (double)N;
     }
-    if (a.node_coef && tid < a.Kmax)
-        a.node_coef[cid * a.Kmax + tid] =
-            tid <= d ? sl->x[tid] + (tid < d ? sl->coefpar[tid] : 0.0) : 0.0;
+    if (tid < a.Kmax) {
+        const double cv = tid <= d ? sl->x[tid] + (tid < d ? sl->coefpar[tid] : 0.0) : 0.0;
+        if (a.node_coef) a.node_coef[cid * a.Kmax + tid] = cv;
+        if (rout) rout[N + TRI(a.Kmax) + tid] = cv;
+    }
 }
 
 __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
@@ -858,15 +903,62 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
 
     PROF_INIT;
     const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
-    const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j);
+    double rnorm2;
+    float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2);
     if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
     if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
     __syncthreads();
+    // Deeper levels need not multiply again: with r = y - sum_i c_i a_i(. - p_i),
+    //   C_r[p, k] = C_y[p, k] - sum_i c_i X[k_i][k][p - p_i],  X = atom cross-correlations (csc_gram_table),
+    // so the node's correlations are the signal's (kept by level 0) minus d table slices.  The fp32 error
+    // then scales with ||y||, not ||r||: the candidate band is widened accordingly, and a node whose
+    // residual has collapsed (||r|| < ||y|| / 64) still takes the GEMM on its own residual.
+    bool from_tables = false;
+    if (d > 0 && a.gram && a.mode == 0) {
+        const double y2 = a.ynorm2[s];
+        if (rnorm2 * 4096.0 >= y2) {
+            from_tables = true;
+            float csum = 0.f;
+            for (int i = 0; i < d; ++i) csum += fabsf((float)sl->coefpar[i]);
+            delta = DELTA_REL * (float)sqrt(y2) + 9.5367431640625e-07f * csum;
+        }
+    }
 
     PROF_MARK(0);
     // ---- correlations on the matrix cores ------------------------------------------------------------
     f32x4 acc[MT][NT];
-    corr_tile_gemm(a.bank32t, sl->masks, (L + SLAB - 1) / SLAB, r32 + 64 * wave + lr + lq, slab, acc);
+    if (from_tables) {
+        const int prow0 = 64 * wave + 4 * lq;
+        const float* c0p = a.c0 + ((size_t)s * CSC_TILE_COLS + lr) * CSC_TILE_ROWS + prow0;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+                acc[mi][ni] = *reinterpret_cast<const f32x4*>(c0p + ni * 16 * CSC_TILE_ROWS + 16 * mi);
+        for (int i = 0; i < d; ++i) {
+            const float ci = (float)sl->coefpar[i];
+            const float* gp = a.gram + ((size_t)sl->sup_atom[i] * CSC_TILE_COLS + lr) * GRAM_W +
+                              (prow0 - sl->sup_pos[i] + P - 1);
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    const f32x4 g = *reinterpret_cast<const f32x4u*>(gp + ni * 16 * GRAM_W + 16 * mi);
+                    acc[mi][ni] -= ci * g;
+                }
+        }
+    } else {
+        corr_tile_gemm(a.bank32t, sl->masks, (L + SLAB - 1) / SLAB, r32 + 64 * wave + lr + lq, slab, acc);
+        if (d == 0 && a.c0) {                                        // keep the signal's correlations for the levels below
+            float* c0p = a.c0 + ((size_t)s * CSC_TILE_COLS + lr) * CSC_TILE_ROWS + 64 * wave + 4 * lq;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+                    *reinterpret_cast<f32x4*>(c0p + ni * 16 * CSC_TILE_ROWS + 16 * mi) = acc[mi][ni];
+            if (tid == 0) a.ynorm2[s] = rnorm2;
+        }
+    }
 
     PROF_MARK(1);
     int permv[NT];                                // atom of this lane's column in tile ni (-1 = padding)
@@ -1155,7 +1247,8 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled_kernel(const LevelArgs 
         if ((long long)j + (long long)r * stride < Fc) ++nch; else break;
     }
     const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
-    const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j);
+    double rnorm2;
+    const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2);
 
     f32x4 acc[MT][NT];
     int permv[NT];
@@ -1434,7 +1527,7 @@ static inline void timer_end(hipStream_t st, int i) {
 
 extern "C" {
 
-int csc_abi_version(void) { return 1; }
+int csc_abi_version(void) { return 2; }
 const char* csc_last_error(void) { return g_err; }
 
 size_t csc_bank32_elems(int K, int L) {
@@ -1504,16 +1597,41 @@ int csc_tree_nodes(int max_sparsity, int connections, int branches, int* level_s
     return nn;
 }
 
-size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections, int branches) {
-    TreeShape ts;
-    if (make_shape(max_sparsity, connections, branches, &ts) < 0 || S <= 0 || N <= 0) return 0;
+static size_t node_ws_bytes(int S, int N, int max_sparsity, const TreeShape& ts) {
     int fmax = 1;
     for (int d = 1; d < max_sparsity; ++d) fmax = ts.F[d] > fmax ? ts.F[d] : fmax;
-    return 2 * (size_t)S * fmax * (N + TRI(max_sparsity)) * sizeof(double);
+    return 2 * (size_t)S * fmax * (N + TRI(max_sparsity) + max_sparsity) * sizeof(double);
+}
+
+size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections, int branches, int with_gram) {
+    TreeShape ts;
+    if (make_shape(max_sparsity, connections, branches, &ts) < 0 || S <= 0 || N <= 0) return 0;
+    size_t b = node_ws_bytes(S, N, max_sparsity, ts);
+    if (with_gram) b += (size_t)S * CSC_TILE_COLS * CSC_TILE_ROWS * sizeof(float) + (size_t)S * sizeof(double);
+    return b;
+}
+
+size_t csc_gram_elems(int K, int L, int N) {
+    const int P = N - L + 1;
+    if (K <= 0 || K > CSC_TILE_COLS || P <= 0 || P > CSC_TILE_ROWS) return 0;
+    return (size_t)K * CSC_TILE_COLS * GRAM_W;
+}
+
+int csc_gram_table(const double* d_bank64, const float* d_bank32t, int K, int L, int N, float* d_gram,
+                   void* stream) {
+    const int P = N - L + 1;
+    if (!d_bank64 || !d_bank32t || !d_gram || K <= 0 || L <= 0) FAIL(-1, "csc_gram_table: bad arguments");
+    if (csc_gram_elems(K, L, N) == 0)
+        FAIL(-9, "csc_gram_table: needs K <= %d and 1 <= P <= %d (got K = %d, P = %d)", CSC_TILE_COLS,
+             CSC_TILE_ROWS, K, P);
+    clear_stale_error();
+    hipLaunchKernelGGL(gram_table_kernel, dim3(CSC_TILE_COLS, K), dim3(WG), (size_t)2 * L * sizeof(double),
+                       (hipStream_t)stream, d_bank64, bank_meta(d_bank32t, K, L), K, L, P, d_gram);
+    return launch_status("gram_table_kernel");
 }
 
 static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
-                      int K, int L, const double* d_signals, int S, int N,
+                      const float* d_gram, int K, int L, const double* d_signals, int S, int N,
                       int max_sparsity, int connections, int branches,
                       void* d_workspace, size_t workspace_bytes,
                       int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse,
@@ -1535,7 +1653,9 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         FAIL(-9, "dictionary (K = %d, P = %d) exceeds %d (256 x 144) units per node", K, P, MAX_UNITS);
     if (n_slabs(L) > MAX_SLABS) FAIL(-8, "atom length %d exceeds %d", L, MAX_SLABS * SLAB);
     if (max_sparsity > P * K) FAIL(-2, "max_sparsity exceeds the number of activations");
-    const size_t need = csc_mmpdf_workspace_bytes(S, N, max_sparsity, connections, branches);
+    const bool gram = d_gram && !tiled && mode == 0 && max_sparsity > 1;
+    const size_t node_bytes = node_ws_bytes(S, N, max_sparsity, ts);
+    const size_t need = csc_mmpdf_workspace_bytes(S, N, max_sparsity, connections, branches, gram ? 1 : 0);
     if (max_sparsity > 1 && (workspace_bytes < need || !d_workspace))
         FAIL(-10, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
     const int Lp = n_slabs(L) * SLAB;                      // residual window zero-padded to whole slabs
@@ -1551,14 +1671,19 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
     hipFuncSetAttribute(tiled ? (const void*)mmp_level_tiled_kernel : (const void*)mmp_level_kernel,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 
-    double* ws[2] = {static_cast<double*>(d_workspace), static_cast<double*>(d_workspace) + need / 16};
+    double* ws[2] = {static_cast<double*>(d_workspace), static_cast<double*>(d_workspace) + node_bytes / 16};
+    float* c0 = gram ? reinterpret_cast<float*>(static_cast<char*>(d_workspace) + node_bytes) : nullptr;
+    double* ynorm2 = gram ? reinterpret_cast<double*>(static_cast<char*>(d_workspace) + node_bytes +
+                                                      (size_t)S * CSC_TILE_COLS * CSC_TILE_ROWS * sizeof(float))
+                          : nullptr;
     hipStream_t st = (hipStream_t)stream;
     for (int d = 0; d < max_sparsity; ++d) {
         LevelArgs a;
         a.bank32t = d_bank32t; a.meta = bank_meta(d_bank32t, K, L); a.bank64 = d_bank64; a.sim_bits = d_sim_bits;
         a.K = K; a.L = L; a.Lp = Lp; a.N = N; a.P = P; a.W = W;
         a.depth = d; a.Kmax = max_sparsity; a.connections = connections; a.NN = NN;
-        a.NS = N + TRI(max_sparsity); a.stagger_ticks = stagger_ticks(); a.mode = mode;
+        a.NS = N + TRI(max_sparsity) + max_sparsity; a.stagger_ticks = stagger_ticks(); a.mode = mode;
+        a.gram = gram ? d_gram : nullptr; a.c0 = c0; a.ynorm2 = ynorm2;
         a.resid_in = (d == 0) ? d_signals : ws[d & 1];
         a.resid_out = (d + 1 < max_sparsity) ? ws[(d + 1) & 1] : nullptr;
         a.node_pos = d_node_pos; a.node_atom = d_node_atom; a.node_mse = d_node_mse; a.node_coef = d_node_coef;
@@ -1583,13 +1708,13 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
 }
 
 int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
-                    int K, int L, const double* d_signals, int S, int N,
+                    const float* d_gram, int K, int L, const double* d_signals, int S, int N,
                     int max_sparsity, int connections, int branches,
                     void* d_workspace, size_t workspace_bytes,
                     int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse,
                     double* d_node_coef, double* d_rec_mse, int32_t* d_rec_leaf,
                     int32_t* d_rec_sel, int32_t* d_stats, void* stream) {
-    return run_levels(0, d_bank32t, d_bank64, d_sim_bits, K, L, d_signals, S, N, max_sparsity, connections,
+    return run_levels(0, d_bank32t, d_bank64, d_sim_bits, d_gram, K, L, d_signals, S, N, max_sparsity, connections,
                       branches, d_workspace, workspace_bytes, d_node_pos, d_node_atom, d_node_mse, d_node_coef,
                       d_rec_mse, d_rec_leaf, d_rec_sel, d_stats, stream);
 }
@@ -1599,7 +1724,7 @@ int csc_mp_batch(const float* d_bank32t, const double* d_bank64, int K, int L, c
                  int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse, double* d_node_mask,
                  int32_t* d_stats, void* stream) {
     if (!d_node_mask && S > 0) FAIL(-1, "csc_mp_batch: d_node_mask is required");
-    return run_levels(1, d_bank32t, d_bank64, nullptr, K, L, d_signals, S, N, iterations, 1, 1, d_workspace,
+    return run_levels(1, d_bank32t, d_bank64, nullptr, nullptr, K, L, d_signals, S, N, iterations, 1, 1, d_workspace,
                       workspace_bytes, d_node_pos, d_node_atom, d_node_mse, d_node_mask, nullptr, nullptr,
                       nullptr, d_stats, stream);
 }

@@ -26,6 +26,7 @@
 extern "C" {
 #endif
 
+#define CSC_ABI_VERSION 2
 #define CSC_TILE_COLS 144      /* atoms per column tile of the correlation kernel (9 x 16)   */
 #define CSC_TILE_ROWS 256      /* positions per row tile (4 waves x 4 x 16)                   */
 #define CSC_MAX_SPARSITY 16    /* largest tree depth / support size                           */
@@ -64,8 +65,21 @@ int csc_correlate(const float* d_bank32t, int K, int L, const double* d_signals,
  * (may be NULL) and returns the number of non-root nodes per signal, or a negative error. */
 int csc_tree_nodes(int max_sparsity, int connections, int branches, int* level_sizes);
 
-/* Bytes of scratch csc_mmpdf_batch needs for S signals. */
-size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections, int branches);
+/* Atom cross-correlation table for the correlation UPDATE of the deeper tree levels (no counterpart in
+ * the reference, which re-correlates every residual, src/csc/mmp.py:69): with the node's residual
+ * r = y - sum_i c_i a_{k_i}(. - p_i),
+ *     C_r[p, k] = C_y[p, k] - sum_i c_i X[k_i][k][p - p_i],   X[ks][k][dp] = sum_j a_k[j] a_ks[j + dp],
+ * so only level 0 multiplies; levels >= 1 read the signal's correlations (kept in the workspace) and one
+ * table slice per ancestor.  Exactness of the selection is kept by the fp64 re-score of every entry in
+ * the (widened) fp32 error band.  Available when the whole correlation matrix fits one register tile:
+ * K <= 144 and 1 <= N - L + 1 <= 256; csc_gram_elems returns 0 otherwise.
+ *   d_gram [K][144][512] f32, column order of d_bank32t (csc_bank_pack must have run). */
+size_t csc_gram_elems(int K, int L, int N);
+int csc_gram_table(const double* d_bank64, const float* d_bank32t, int K, int L, int N, float* d_gram,
+                   void* stream);
+
+/* Bytes of scratch csc_mmpdf_batch needs for S signals (with_gram != 0: a d_gram table is passed). */
+size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections, int branches, int with_gram);
 
 /* Batched MMP-DF / OMP: all signals x frontier nodes per level, one launch per level.
  * Replaces the joblib fan-out over MMPTree(...).runMMPDF(...) of
@@ -73,6 +87,8 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
  * connections = branches = 1, the omp loops of :492-552, :574-649.
  *
  * Node id of (level d, index j) is off_d + j with off_1 = 0, off_{d+1} = off_d + F_d; NN = total.
+ *   d_gram      csc_gram_table output or NULL (NULL: every node correlates its residual on the MFMA
+ *               units; the results are identical either way)
  *   d_signals   [S][N] f64
  *   d_node_pos  [S][NN] int32   selected position of the node      (src/csc/mmp.py:74-76)
  *   d_node_atom [S][NN] int32   selected atom index
@@ -86,10 +102,11 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
  *   d_rec_sel   [S][max_sparsity][max_sparsity][2] int32  (pos, atom) root->leaf of the last-min
  *               leaf, -1 padded                                      (src/csc/mmp.py:257-265)
  *   d_stats     [4] int32 or NULL (must be zeroed by the caller): [0] selections that fell back
- *               to the fp32 arg-max (candidate overflow), [1] non-positive Cholesky pivots
+ *               to the fp32 arg-max (candidate overflow), [1] re-selected activations (dead Cholesky
+ *               columns), [2] number of fp64 re-scored candidates
  */
 int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
-                    int K, int L, const double* d_signals, int S, int N,
+                    const float* d_gram, int K, int L, const double* d_signals, int S, int N,
                     int max_sparsity, int connections, int branches,
                     void* d_workspace, size_t workspace_bytes,
                     int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse,
@@ -105,7 +122,7 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
  *   d_node_mse  [S][iterations]                mean((signal - approx)^2) after it
  *   d_node_mask [S][iterations][iterations]    mask value per support slot after it (slot q = q-th
  *               selection; a re-selected activation accumulates in its first slot, the later slot is 0)
- *   workspace: csc_mmpdf_workspace_bytes(S, N, iterations, 1, 1) bytes. */
+ *   workspace: csc_mmpdf_workspace_bytes(S, N, iterations, 1, 1, 0) bytes. */
 int csc_mp_batch(const float* d_bank32t, const double* d_bank64, int K, int L, const double* d_signals,
                  int S, int N, int iterations, void* d_workspace, size_t workspace_bytes,
                  int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse, double* d_node_mask,

@@ -21,11 +21,11 @@ def test_library_exports_every_declared_symbol():
     from csc_amd import _lib
     lib = _lib.lib()
     names = _declared_symbols()
-    assert len(names) >= 17
+    assert len(names) >= 21
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.EXPORTS) == names
-    assert lib.csc_abi_version() == 1
+    assert lib.csc_abi_version() == 2
 
 
 def test_header_cites_reference_for_every_entry_point():
@@ -56,7 +56,11 @@ def test_sizes_helpers():
     assert lib.csc_sim_words(738, 492) == 2 * ((2 * 247 - 1 + 63) // 64)
     assert lib.csc_sim_words(100, 492) == 0
     # per frontier node: N residual samples + the packed Cholesky factor (15 doubles at depth 5)
-    assert lib.csc_mmpdf_workspace_bytes(10, 738, 5, 3, 3) == 2 * 10 * 3 * (738 + 15) * 8
+    # + max_sparsity coefficients; with the table: the signals' correlations (144 x 256 f32) and norms
+    assert lib.csc_mmpdf_workspace_bytes(10, 738, 5, 3, 3, 0) == 2 * 10 * 3 * (738 + 15 + 5) * 8
+    assert lib.csc_mmpdf_workspace_bytes(10, 738, 5, 3, 3, 1) == 2 * 10 * 3 * (738 + 15 + 5) * 8 + 10 * (144 * 256 * 4 + 8)
+    assert lib.csc_gram_elems(143, 492, 738) == 143 * 144 * 512 and lib.csc_gram_elems(145, 492, 738) == 0
+    assert lib.csc_gram_elems(143, 492, 492 + 256) == 0 and lib.csc_gram_elems(143, 492, 492 + 255) > 0
 
 
 def test_candidate_paths_match_reference_table():

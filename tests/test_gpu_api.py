@@ -14,10 +14,13 @@ from conftest import load_json
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def dic():
+@pytest.fixture(scope="module", params=["tables", "mfma"])
+def dic(request):
+    """every API test runs twice: deeper levels from the cross-correlation table (default) / by GEMM"""
     import csc_amd
-    return csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.005), np.arange(0.010, 0.036, 0.002), [1])
+    d = csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.005), np.arange(0.010, 0.036, 0.002), [1])
+    d.device_bank().use_gram = request.param == "tables"
+    return d
 
 
 def test_native_library_is_loaded(dic):
@@ -244,6 +247,22 @@ def test_config2_depth_truncation_and_determinism(dic, config2):
     for d in range(1, 6):
         assert np.array_equal(omp.node_pos[:, d - 1], res.node_pos[:, res.node_id(d, 0)])
         assert np.array_equal(omp.node_atom[:, d - 1], res.node_atom[:, res.node_id(d, 0)])
+
+
+def test_config2_table_path_equals_mfma_path(dic, config2):
+    """the two correlation paths select the same atoms on all 3200 signals; MSE to 1e-12"""
+    sigs, _, res = config2
+    bank = dic.device_bank()
+    old = bank.use_gram
+    try:
+        bank.use_gram = not old
+        other = bank.mmpdf_batch(sigs, 5, 3, 3, 0.8, want_coef=True)
+    finally:
+        bank.use_gram = old
+    assert other.stats[0] == 0
+    assert np.array_equal(other.node_pos, res.node_pos) and np.array_equal(other.node_atom, res.node_atom)
+    assert np.allclose(other.node_mse, res.node_mse, rtol=1e-12, atol=0)
+    assert np.allclose(other.node_coef, res.node_coef, rtol=1e-10, atol=1e-14)
 
 
 def test_config2_vs_oracle_sample(dic, config2, oracle_dict):

@@ -15,10 +15,33 @@ from conftest import GOLDEN, load_json
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def bank(golden_bank):
+@pytest.fixture(scope="module", params=["tables", "mfma"])
+def bank(request, golden_bank):
+    """both ways of getting a deeper node's correlations: from the cross-correlation table (default) and
+    by a GEMM on the node's residual"""
     from csc_amd.engine import DeviceBank
-    return DeviceBank(golden_bank["bank"])
+    b = DeviceBank(golden_bank["bank"])
+    b.use_gram = request.param == "tables"
+    return b
+
+
+def test_gram_table(bank, golden_bank):
+    if not bank.use_gram:
+        pytest.skip("table path only")
+    b = golden_bank["bank"]
+    K, L = b.shape
+    P = 738 - L + 1
+    g = bank.gram_table(738).cpu().numpy().reshape(K, 144, 512)
+    perm = bank.bank32t.cpu().numpy()[16 * 9 * 512:].view(np.int32)[:144]
+    assert not g[:, perm < 0].any() and not g[:, :, 2 * P - 1:].any()
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        ks, c, dp = rng.integers(K), rng.integers(1, 144), rng.integers(-(P - 1), P)
+        k = perm[c]
+        lo, hi = max(0, -dp), min(L, L - dp)
+        want = float(np.dot(b[k, lo:hi], b[ks, lo + dp:hi + dp]))
+        assert abs(g[ks, c, dp + P - 1] - want) <= 1e-7 * max(1.0, abs(want)), (ks, c, dp)
+    assert bank.lib.csc_gram_elems(K, L, L + 256) == 0          # P = 257: no table, the GEMM path is used
 
 
 def test_bank_pack(bank, golden_bank):
