@@ -14,10 +14,13 @@ already resident in HBM; with N > 1 every rank holds its own 3200 signals (weak 
 step ends with the ONE gather of the fixed-size sparVar records on rank 0 over RCCL.
 
 Reported next to `value`:
-  roofline      fp32 MFMA roofline of the dominant kernel (mmp_level_kernel), launch durations
-                measured live with HIP events on the launch stream (csc_timer in include/csc_hip.h).
-                Algorithmic flops per signal = n_sel * 2*P*K*L, n_sel = 1 + sum_{d<5} min(B, c^d) = 13
-                (dense semantics of the reference, zero padding of the atoms NOT discounted).
+  roofline      memory roofline of the dominant kernel (mmp_level_kernel), launch durations measured
+                live with HIP events on the launch stream (csc_timer in include/csc_hip.h).  Level 0
+                correlates on fp32 MFMA; deeper nodes read the signal's correlations and one slice of the
+                atom cross-correlation table per ancestor (algorithmic bytes: DESIGN.md section 4).
+  mfma_path     the same batch with every node multiplied on the matrix cores, against the fp32 MFMA
+                peak: algorithmic flops per signal = n_sel * 2*P*K*L, n_sel = 13 (dense semantics of the
+                reference, zero padding of the atoms NOT discounted).
   cpu_baseline  the oracle's reference-faithful mode (oaconvolve over all atoms + lsqr defaults + one
                 fresh tree per sparsity = the reference's cost structure; kind "port" because the
                 reference's files cannot travel to the GPU box) on a bounded sample, rank 0, N = 1 only.
@@ -39,6 +42,7 @@ CONNECTIONS, BRANCHES, MAX_SPARSITY, DISSIMILARITY = 3, 3, 5, 0.8
 SIGNAL_LENGTH, PER_CELL = 738, 200
 SNR_LEVELS, SPARSITY_LEVELS = [0, 5, 10, 15], [2, 3, 4, 5]
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0              # same guide, "HBM3E peak BW" (spec); 6.29 TB/s measured copy rate
 CPU_SAMPLE = [i * PER_CELL + 7 for i in (0, 3, 5, 6, 9, 10, 12, 15)]   # one signal in 8 of the 16 cells
 
 
@@ -103,6 +107,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--per-cell", type=int, default=PER_CELL, help="signals per (snr, sparsity) cell per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mfma-leg", action="store_true", help="skip the all-MFMA comparison run (profiling)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -184,20 +189,66 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # the same batch with every node correlated on the matrix cores (no cross-correlation table): the
+    # "% of fp32 MFMA peak" leg of BASELINE.json's metric; outside the timed region, no collective
+    spans_m, mfma_elapsed, msteps, same = [], 0.0, 0, None
+    if not a.no_mfma_leg:
+        bank.use_gram = False
+        out_m = bank.mmpdf_launch(d_sig, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY, want_coef=False)
+        torch.cuda.synchronize(dev)
+        msteps = max(2, min(5, a.steps))
+        timer_m = _lib.LevelTimer(capacity=msteps * MAX_SPARSITY)
+        t0 = time.perf_counter()
+        with timer_m:
+            for _ in range(msteps):
+                bank.mmpdf_launch(d_sig, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY, want_coef=False, out=out_m)
+            torch.cuda.synchronize(dev)
+        mfma_elapsed = time.perf_counter() - t0
+        spans_m = timer_m.read()
+        timer_m.close()
+        bank.use_gram = True
+        same = bool(torch.equal(out_m["rec_buf"], out["rec_buf"]))
+
     if rank == 0:
         ms_step = elapsed / a.steps * 1e3
         value = world * S * a.steps / elapsed
         launch_ms = float(np.mean([ms for _, ms in spans]))
         per_level = {str(d): float(np.mean([ms for lv, ms in spans if lv == d])) for d in range(MAX_SPARSITY)}
-        flops_per_launch = S * flops_per_signal / MAX_SPARSITY       # 5 level launches share n_sel nodes
-        achieved = flops_per_launch / (launch_ms * 1e-3) / 1e12
-        # MFMA flops actually issued: (32-row x 16-atom) blocks holding only the atoms' zero padding are
-        # skipped, every other block costs 4 waves x 32 v_mfma_f32_16x16x4_f32 (2048 flop each) per node
-        meta = bank.bank32t[-208:].view(torch.int32).cpu().numpy()
-        nslab = (L + 31) // 32
-        blocks = sum(9 - (int(m) & -int(m)).bit_length() + 1 for m in meta[144:144 + nslab] if m)
-        issued_per_node = blocks * 4 * 32 * 2048.0
-        issued = S * n_sel * issued_per_node / MAX_SPARSITY / (launch_ms * 1e-3) / 1e12
+        # ---- algorithmic bytes of the default path: level 0 multiplies and keeps the
+        # signal's correlations C_y (K*P f32); a selecting node at depth d >= 1 reads C_y and d slices of the
+        # atom cross-correlation table (K*P f32 each) plus its workspace entry (residual + factor + coefficients)
+        KP4 = K * P * 4.0
+        node_ws = (N + MAX_SPARSITY * (MAX_SPARSITY + 1) // 2 + MAX_SPARSITY) * 8.0
+        bytes_per_signal = N * 8.0 + KP4 + sum(sizes[d - 1] * ((1 + d) * KP4 + 2 * node_ws)
+                                               for d in range(1, MAX_SPARSITY))
+        bytes_per_launch = S * bytes_per_signal / MAX_SPARSITY
+        achieved_gbs = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        dense_tflops = S * flops_per_signal / MAX_SPARSITY / (launch_ms * 1e-3) / 1e12
+        # ---- MFMA leg ---------------------------------------------------------------------------------------
+        mfma_path = None
+        if spans_m:
+            launch_ms_m = float(np.mean([ms for _, ms in spans_m]))
+            flops_per_launch = S * flops_per_signal / MAX_SPARSITY   # 5 level launches share n_sel nodes
+            achieved = flops_per_launch / (launch_ms_m * 1e-3) / 1e12
+            # MFMA flops actually issued: (32-row x 16-atom) blocks holding only the atoms' zero padding are
+            # skipped, every other block costs 4 waves x 32 v_mfma_f32_16x16x4_f32 (2048 flop each) per node
+            meta = bank.bank32t[-208:].view(torch.int32).cpu().numpy()
+            nslab = (L + 31) // 32
+            blocks = sum(9 - (int(m) & -int(m)).bit_length() + 1 for m in meta[144:144 + nslab] if m)
+            issued = S * n_sel * blocks * 4 * 32 * 2048.0 / MAX_SPARSITY / (launch_ms_m * 1e-3) / 1e12
+            mfma_path = {
+                "note": "same batch with the table disabled: every node correlates its residual on the matrix "
+                        "cores (DeviceBank.use_gram = False); identical records: %s" % same,
+                "value": S * msteps / mfma_elapsed, "unit": "signals/s",
+                "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                             "launch_ms_avg": launch_ms_m, "flops_per_launch": flops_per_launch,
+                             "flops_per_signal": flops_per_signal,
+                             "mfma_issued": {"tflops": issued, "frac_of_peak": issued / FP32_MFMA_PEAK_TFLOPS,
+                                             "blocks_per_node": blocks, "of_dense_blocks": nslab * 9,
+                                             "note": "`achieved` counts the reference's dense 2*P*K*L flops per "
+                                                     "node; bank blocks that are all zero padding are skipped, "
+                                                     "so fewer flops are issued"}}}
         traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):
@@ -215,16 +266,19 @@ def main():
                        "nodes_per_signal": NN, "parallelism": f"signals sharded over {world} rank(s), "
                                                               "one RCCL gather of the sparVar records per step"
                                                               if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mmp_level_kernel", "launch_ms_avg": launch_ms, "launch_ms_by_level": per_level,
-                         "flops_per_launch": flops_per_launch, "flops_per_signal": flops_per_signal,
+                         "bytes_per_launch": bytes_per_launch, "bytes_per_signal": bytes_per_signal,
                          "launches_timed": len(spans),
-                         "mfma_issued": {"tflops": issued, "frac_of_peak": issued / FP32_MFMA_PEAK_TFLOPS,
-                                         "blocks_per_node": blocks, "of_dense_blocks": nslab * 9,
-                                         "note": "`achieved` counts the reference's dense 2*P*K*L flops per "
-                                                 "node; the kernel skips bank blocks that are all zero padding, "
-                                                 "so the matrix cores issue fewer flops than that"}},
+                         "note": "level 0 correlates on fp32 MFMA; levels 1-4 (80 % of the time) stream the signal's "
+                                 "correlations and cross-correlation table slices, so the launch average is "
+                                 "memory-bound; the table (42 MB) is served from the Infinity Cache",
+                         "dense_flops_equivalent": {"tflops": dense_tflops,
+                                                    "frac_of_fp32_mfma_peak": dense_tflops / FP32_MFMA_PEAK_TFLOPS,
+                                                    "note": "the reference's 2*P*K*L flops per selecting node, "
+                                                            "had every node been multiplied"}},
+            "mfma_path": mfma_path,
             "cpu_baseline": cpu,
             "pcie_inclusive": {"value": S / pcie_s, "unit": "signals/s",
                                "note": "one call: host f64 signals -> HBM, solve, sparVar records -> host",
