@@ -43,6 +43,7 @@
 #define TRI(n) ((n) * ((n) + 1) / 2)
 #define DELTA_REL 6.103515625e-05f      // 2^-14: fp32 candidate band, in units of ||residual||
 #define GRAM_W (2 * CSC_TILE_ROWS)     // shifts per (atom, column) row of the cross-correlation table
+#define GRAM_MAX_DEPTH 6               // a node at depth d streams (1 + d) x 147 KB; past ~7 slices the GEMM is cheaper
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte access
@@ -914,7 +915,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     // then scales with ||y||, not ||r||: the candidate band is widened accordingly, and a node whose
     // residual has collapsed (||r|| < ||y|| / 64) still takes the GEMM on its own residual.
     bool from_tables = false;
-    if (d > 0 && a.gram && a.mode == 0) {
+    if (d > 0 && d <= GRAM_MAX_DEPTH && a.gram && a.mode == 0) {
         const double y2 = a.ynorm2[s];
         if (rnorm2 * 4096.0 >= y2) {
             from_tables = true;
