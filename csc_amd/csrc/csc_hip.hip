@@ -621,6 +621,24 @@ struct NodeLds {
     float m32;
 };
 
+// Block -> (signal, frontier index).  Workgroups whose blockIdx agree mod 8 share an XCD (and its L2):
+// the F_d nodes of one signal are given consecutive such blocks, so the signal's correlations C_y, which
+// each of them reads, are fetched from HBM once and found in L2 by the siblings.  Pure placement hint:
+// any mapping is correct.
+__device__ __forceinline__ void node_of_block(int Fd, size_t& s, int& j) {
+    const unsigned b = blockIdx.x;
+    const unsigned S = gridDim.x / (unsigned)Fd;
+    const unsigned nfull = (S & ~7u) * (unsigned)Fd;
+    if (b < nfull) {
+        const unsigned xcd = b & 7u, t = b >> 3;
+        s = (size_t)(t / (unsigned)Fd) * 8u + xcd;
+        j = (int)(t % (unsigned)Fd);
+    } else {
+        s = b / (unsigned)Fd;
+        j = (int)(b - (unsigned)s * (unsigned)Fd);
+    }
+}
+
 // ---- pieces of a node's work shared by the register-resident and the tiled level kernels ------------
 
 // residual -> LDS (fp64 + fp32 window copy), ancestors' (pos, atom), parent's coefficients and Cholesky
@@ -883,8 +901,9 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
 
     // ---- which node ------------------------------------------------------------------------------
     const int Fd = a.ts.F[d], Fc = a.ts.F[d + 1];
-    const size_t s = blockIdx.x / Fd;
-    const int j = (int)(blockIdx.x - s * Fd);
+    size_t s;
+    int j;
+    node_of_block(Fd, s, j);
     const int stride = a.ts.pw[d];
     int nch = 0;
     for (int r = 0; r < a.connections; ++r) {
@@ -1240,8 +1259,9 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled_kernel(const LevelArgs 
     TiledLds* tl2 = reinterpret_cast<TiledLds*>(sl + 1);
 
     const int Fd = a.ts.F[d], Fc = a.ts.F[d + 1];
-    const size_t s = blockIdx.x / Fd;
-    const int j = (int)(blockIdx.x - s * Fd);
+    size_t s;
+    int j;
+    node_of_block(Fd, s, j);
     const int stride = a.ts.pw[d];
     int nch = 0;
     for (int r = 0; r < a.connections; ++r) {
