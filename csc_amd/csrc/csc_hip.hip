@@ -43,22 +43,27 @@
 #define TRI(n) ((n) * ((n) + 1) / 2)
 #define DELTA_REL 6.103515625e-05f      // 2^-14: fp32 candidate band, in units of ||residual||
 #define GRAM_W (2 * CSC_TILE_ROWS)     // shifts per (atom, column) row of the cross-correlation table
+#define EX_CAP 512                     // entries of the fp16 first pass that are re-evaluated in fp32
 #define GRAM_MAX_DEPTH 6               // a node at depth d streams (1 + d) x 147 KB; past ~7 slices the GEMM is cheaper
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte access
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 8-byte access
 
-// Development aid (make prof): per-phase shader-clock totals of mmp_level_kernel, summed over workgroups.
+// Development aid (make prof): per-phase shader-clock totals of the level kernels, summed over workgroups
+// (slots 0-15: mmp_level_kernel, 16-31: mmp_level_table_kernel; scripts/phase_prof.py names them).
 #ifdef CSC_PHASE_PROF
-__device__ unsigned long long g_prof[16];
-#define PROF_INIT unsigned long long prof_t = __builtin_readcyclecounter()
-#define PROF_MARK(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) { unsigned long long n_ = __builtin_readcyclecounter(); \
-    atomicAdd(&g_prof[i], n_ - prof_t); prof_t = n_; } } while (0)
-#define PROF_MARK_EXT(i)          /* marks inside shared device functions are not timed separately */
+__device__ unsigned long long g_prof[32];
+#define PROF_FIELDS unsigned long long prof_t; int prof_base;
+#define PROF_INIT(base) do { if (threadIdx.x == 0) { sl->prof_base = (base); sl->prof_t = __builtin_readcyclecounter(); } } while (0)
+#define PROF_MARK(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) { \
+    unsigned long long n_ = __builtin_readcyclecounter(); \
+    atomicAdd(&g_prof[sl->prof_base + (i)], n_ - sl->prof_t); sl->prof_t = n_; } } while (0)
 #else
-#define PROF_INIT
+#define PROF_FIELDS
+#define PROF_INIT(base)
 #define PROF_MARK(i)
-#define PROF_MARK_EXT(i)
 #endif
 
 static thread_local char g_err[256] = "";
@@ -83,8 +88,13 @@ struct LevelArgs {
     int32_t* node_pos; int32_t* node_atom; double* node_mse; double* node_coef;
     int32_t* stats;
     const float* gram;    // atom cross-correlation table [K][144][GRAM_W] f32 or nullptr (always the GEMM)
+    const _Float16* gram16;  // the same table in fp16, two copies ([2][K][144][GRAM_W]; copy 1 shifted by one
+                          // element so that every 4-element window starts dword-aligned), or nullptr
     float* c0;            // [S][144][256] f32: correlations of the ORIGINAL signals, written by level 0
+    _Float16* c0h;        // [S][144][256] f16: the same divided by ||y|| (first-pass operand)
     double* ynorm2;       // [S] squared norm of the original signals, written by level 0
+    uint8_t* flags;       // [S][F[d]] table kernel -> deferred GEMM launch: 1 = this node still needs the GEMM
+    int group, S;         // deferred launch: nodes per workgroup; number of signals
     TreeShape ts;
 };
 
@@ -401,15 +411,18 @@ __global__ __launch_bounds__(WG) void sim_table_kernel(const double* __restrict_
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void gram_table_kernel(const double* __restrict__ bank64,
                                                         const int32_t* __restrict__ meta, int K, int L, int P,
-                                                        float* __restrict__ gram) {
+                                                        float* __restrict__ gram, _Float16* __restrict__ gram16) {
     extern __shared__ double sm[];
     double* a_sel = sm;            // [L]
     double* a_k = sm + L;          // [L]
     const int ksel = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
     const int k = meta[c];
     float* row = gram + ((size_t)ksel * CSC_TILE_COLS + c) * GRAM_W;
+    // fp16 copies: h0[j] = X[j], h1[j] = X[j - 1] (so a 4-element window at an odd j starts dword-aligned in h1)
+    _Float16* h0 = gram16 + ((size_t)ksel * CSC_TILE_COLS + c) * GRAM_W;
+    _Float16* h1 = h0 + (size_t)K * CSC_TILE_COLS * GRAM_W;
     if (k < 0) {                                                     // padding column
-        for (int i = tid; i < GRAM_W; i += WG) row[i] = 0.f;
+        for (int i = tid; i < GRAM_W; i += WG) { row[i] = 0.f; h0[i] = (_Float16)0.f; h1[i] = (_Float16)0.f; }
         return;
     }
     for (int i = tid; i < L; i += WG) {
@@ -425,6 +438,9 @@ __global__ __launch_bounds__(WG) void gram_table_kernel(const double* __restrict
             for (int j = j0; j < j1; ++j) acc = fma(a_k[j], a_sel[j + dp], acc);
         }
         row[dpi] = (float)acc;
+        h0[dpi] = (_Float16)(float)acc;
+        if (dpi + 1 < GRAM_W) h1[dpi + 1] = (_Float16)(float)acc;
+        if (dpi == 0) h1[0] = (_Float16)0.f;
     }
 }
 
@@ -619,6 +635,11 @@ struct NodeLds {
     int widx[WG / 64], wsupp[WG / 64];
     int cand_cnt, chosen, i32, bad, odd_slot;
     float m32;
+    int ex_cnt, any_supp;
+    int sib_pos[CSC_MAX_CONNECTIONS], sib_atom[CSC_MAX_CONNECTIONS];
+    int ex_idx[EX_CAP];            // fp16 first pass: flattened index and fp32 value of the entries in its band
+    float ex_val[EX_CAP];
+    PROF_FIELDS
 };
 
 // Block -> (signal, frontier index).  Workgroups whose blockIdx agree mod 8 share an XCD (and its L2):
@@ -649,7 +670,7 @@ __device__ __forceinline__ float node_prologue(const LevelArgs& a, NodeLds* sl, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, d = a.depth;
     double ss = 0.0;
-    for (int i0 = 0; i0 < R32; i0 += 4 * WG) {                        // R32 > Npad: one sweep fills both copies
+    for (int i0 = 0; i0 < max(R32, Npad); i0 += 4 * WG) {              // one sweep fills both copies
         double v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -799,7 +820,7 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
         }
     }
     __syncthreads();
-    PROF_MARK_EXT(4);
+    PROF_MARK(6);
     if (tid == 0) {
         // factor row: Lf y = g, l_dd^2 = g_dd - y.y.  A dead column (an activation selected twice,
         // src/csc/mmp.py:56 sets the same mask bit again) has diagonal 0 and is skipped everywhere.
@@ -834,7 +855,7 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
         if (bad && a.stats) atomicAdd(&a.stats[1], 1);
     }
     __syncthreads();
-    PROF_MARK_EXT(5);
+    PROF_MARK(7);
     // ---- child residual, factor, MSE ------------------------------------------------------------------
     double* rout = a.resid_out ? a.resid_out + (s * Fc + jc) * (size_t)a.NS : nullptr;
     double cs = 0.0;
@@ -882,111 +903,134 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
         if (a.node_coef) a.node_coef[cid * a.Kmax + tid] = cv;
         if (rout) rout[N + TRI(a.Kmax) + tid] = cv;
     }
+    PROF_MARK(8);
 }
 
-__global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
-    extern __shared__ double lds_raw[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lr = lane & 15, lq = lane >> 4;
-    const int N = a.N, K = a.K, L = a.L, Lp = a.Lp, P = a.P, d = a.depth;
+// ---- the correlations of a node held in registers: two layouts -------------------------------------------
+// f32x4 acc[MT][NT] (144 values per lane) holds the (256 positions x 144 bank columns) correlation tile.
+//   MFMA layout (ROWS = false, mmp_level_kernel): what v_mfma_f32_16x16x4 leaves behind,
+//       position 64*wave + 16*mi + 4*(lane>>4) + rg, bank column 16*ni + (lane&15)
+//   row layout (ROWS = true, mmp_level_table_kernel): a wave instruction covers one whole bank column,
+//       position 4*lane + rg, bank column 36*wave + 9*mi + ni
+//     so every table load is one contiguous kilobyte (the MFMA layout touches 16 rows of 64 bytes each).
+template <bool ROWS>
+__device__ __forceinline__ int entry_pos(int mi, int rg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    return ROWS ? 4 * lane + rg : 64 * wave + 16 * mi + 4 * (lane >> 4) + rg;
+}
+template <bool ROWS>
+__device__ __forceinline__ int entry_col(int mi, int ni) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    return ROWS ? 36 * wave + NT * mi + ni : 16 * ni + (lane & 15);
+}
 
-    // ---- LDS carve-up ---------------------------------------------------------------------------
-    const int Npad = (N + 3) & ~3;
-    const int R32 = CSC_TILE_ROWS + Lp + 4;
-    float* slab = reinterpret_cast<float*>(lds_raw);                  // [2][SLABF]
-    uint32_t* simrow = reinterpret_cast<uint32_t*>(slab);             // aliases the slabs
-    double* r64 = lds_raw + SLABF;                                    // [Npad]   (2*SLABF floats = SLABF doubles)
-    float* r32 = reinterpret_cast<float*>(r64 + Npad);                // [R32]
-    NodeLds* sl = reinterpret_cast<NodeLds*>(r32 + ((R32 + 3) & ~3));
+// Nine table columns (one mi row of acc) per batch, two batches in flight.  pin() makes the nine loaded vectors
+// live at one point, so the nine loads are issued back to back and waited for once: left to itself the
+// compiler, short of registers next to the 144 accumulators, issues one load at a time with a full
+// s_waitcnt after each, and the table path then runs at the latency, not the bandwidth, of the memory.
+template <typename V>
+__device__ __forceinline__ void pin(V (&b)[NT]) {
+    asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]),
+                      "+v"(b[7]), "+v"(b[8]));
+}
+template <typename VU, typename V, typename T>
+__device__ __forceinline__ void load_cols(const T* gp, int mi, V (&b)[NT]) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) b[ni] = *reinterpret_cast<const VU*>(gp + (NT * mi + ni) * GRAM_W);
+}
+__device__ __forceinline__ void sub_cols(f32x4 (&acc)[NT], float ci, const f32x4 (&b)[NT]) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[ni] -= ci * b[ni];
+}
+__device__ __forceinline__ void sub_cols(f32x4 (&acc)[NT], float ci, const f16x4 (&b)[NT]) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[ni] -= ci * __builtin_convertvector(b[ni], f32x4);
+}
 
-    // ---- which node ------------------------------------------------------------------------------
-    const int Fd = a.ts.F[d], Fc = a.ts.F[d + 1];
-    size_t s;
-    int j;
-    node_of_block(Fd, s, j);
-    const int stride = a.ts.pw[d];
-    int nch = 0;
-    for (int r = 0; r < a.connections; ++r) {
-        if ((long long)j + (long long)r * stride < Fc) ++nch; else break;
-    }
-
-    // ---- optional start-up stagger: the two workgroups that share a CU at launch would otherwise
-    //      run their MFMA phases and their selection phases in lock-step ---------------------------------
-    if (a.stagger_ticks > 0 && blockIdx.x < 2 * 256) {
-        if (tid == 0) sl->odd_slot = (int)(__builtin_amdgcn_s_getreg(63492) & 1u);   // HW_ID.WAVE_ID bit 0
-        __syncthreads();
-        if (sl->odd_slot) {
-            const unsigned long long t0 = wall_clock64();
-            while (wall_clock64() - t0 < (unsigned long long)a.stagger_ticks) __builtin_amdgcn_s_sleep(32);
-        }
-    }
-
-    PROF_INIT;
-    const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
-    double rnorm2;
-    float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2);
-    if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
-    if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
-    __syncthreads();
-    // Deeper levels need not multiply again: with r = y - sum_i c_i a_i(. - p_i),
-    //   C_r[p, k] = C_y[p, k] - sum_i c_i X[k_i][k][p - p_i],  X = atom cross-correlations (csc_gram_table),
-    // so the node's correlations are the signal's (kept by level 0) minus d table slices.  The fp32 error
-    // then scales with ||y||, not ||r||: the candidate band is widened accordingly, and a node whose
-    // residual has collapsed (||r|| < ||y|| / 64) still takes the GEMM on its own residual.
-    bool from_tables = false;
-    if (d > 0 && d <= GRAM_MAX_DEPTH && a.gram && a.mode == 0) {
-        const double y2 = a.ynorm2[s];
-        if (rnorm2 * 4096.0 >= y2) {
-            from_tables = true;
-            float csum = 0.f;
-            for (int i = 0; i < d; ++i) csum += fabsf((float)sl->coefpar[i]);
-            delta = DELTA_REL * (float)sqrt(y2) + 9.5367431640625e-07f * csum;
-        }
-    }
-
-    PROF_MARK(0);
-    // ---- correlations on the matrix cores ------------------------------------------------------------
-    f32x4 acc[MT][NT];
-    if (from_tables) {
-        const int prow0 = 64 * wave + 4 * lq;
-        const float* c0p = a.c0 + ((size_t)s * CSC_TILE_COLS + lr) * CSC_TILE_ROWS + prow0;
+// row layout from the tables: acc = C_y - sum_i c_i X_i
+__device__ __forceinline__ void fill_from_tables32(const LevelArgs& a, const NodeLds* sl, size_t s, int d, int P,
+                                                   f32x4 (&acc)[MT][NT]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* c0p = a.c0 + ((size_t)s * CSC_TILE_COLS + 36 * wave) * CSC_TILE_ROWS + 4 * lane;
+    const float* gbase = a.gram + (size_t)36 * wave * GRAM_W + (4 * lane + P - 1);
+    const size_t astride = (size_t)CSC_TILE_COLS * GRAM_W;
+    f32x4 A[NT], B[NT];
+    const float* gp = gbase + sl->sup_atom[0] * astride - sl->sup_pos[0];     // d >= 1
+    load_cols<f32x4u>(gp, 0, A);
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni)
+            acc[mi][ni] = *reinterpret_cast<const f32x4*>(c0p + (NT * mi + ni) * CSC_TILE_ROWS);
+    for (int i = 0; i < d; ++i) {
+        const float ci = (float)sl->coefpar[i];
+        const int in = min(i + 1, d - 1);                            // the last slice is fetched again (one batch)
+        const float* gpn = gbase + sl->sup_atom[in] * astride - sl->sup_pos[in];
+        load_cols<f32x4u>(gp, 1, B);  pin(A); sub_cols(acc[0], ci, A);
+        load_cols<f32x4u>(gp, 2, A);  pin(B); sub_cols(acc[1], ci, B);
+        load_cols<f32x4u>(gp, 3, B);  pin(A); sub_cols(acc[2], ci, A);
+        load_cols<f32x4u>(gpn, 0, A); pin(B); sub_cols(acc[3], ci, B);
+        gp = gpn;
+    }
+}
+
+// the same from the fp16 copies, in units of ||y||: acc = C_y/||y|| - sum_i (c_i/||y||) X16_i
+__device__ __forceinline__ void fill_from_tables16(const LevelArgs& a, const NodeLds* sl, size_t s, int d, int P,
+                                                   float ynorm, f32x4 (&acc)[MT][NT]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const _Float16* c0p = a.c0h + ((size_t)s * CSC_TILE_COLS + 36 * wave) * CSC_TILE_ROWS + 4 * lane;
+    const float inv = 1.f / ynorm;
+    const size_t copy = (size_t)a.K * CSC_TILE_COLS * GRAM_W;        // elements of one fp16 copy
+    const size_t astride = (size_t)CSC_TILE_COLS * GRAM_W;
+    const _Float16* gbase = a.gram16 + (size_t)36 * wave * GRAM_W;
+    // element j0 = 4*lane + P - 1 - p_i of the slice; copy (j0 & 1) holds X shifted by (j0 & 1): 4-byte aligned
+    auto slice = [&](int i) {
+        const int j0 = 4 * lane + P - 1 - sl->sup_pos[i], par = j0 & 1;       // par is block-uniform
+        return gbase + par * copy + sl->sup_atom[i] * astride + j0 + par;
+    };
+    f16x4 A[NT], B[NT];
+    const _Float16* gp = slice(0);                                   // d >= 1
+    load_cols<f16x4u>(gp, 0, A);
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+            acc[mi][ni] = __builtin_convertvector(
+                *reinterpret_cast<const f16x4*>(c0p + (NT * mi + ni) * CSC_TILE_ROWS), f32x4);
+    for (int i = 0; i < d; ++i) {
+        const float ci = (float)sl->coefpar[i] * inv;
+        const _Float16* gpn = slice(min(i + 1, d - 1));
+        load_cols<f16x4u>(gp, 1, B);  pin(A); sub_cols(acc[0], ci, A);
+        load_cols<f16x4u>(gp, 2, A);  pin(B); sub_cols(acc[1], ci, B);
+        load_cols<f16x4u>(gp, 3, B);  pin(A); sub_cols(acc[2], ci, A);
+        load_cols<f16x4u>(gpn, 0, A); pin(B); sub_cols(acc[3], ci, B);
+        gp = gpn;
+    }
+}
+
+// entries outside the (P x K) matrix never win: positions >= P and padding columns
+template <bool ROWS>
+__device__ __forceinline__ void mask_outside(const NodeLds* sl, f32x4 (&acc)[MT][NT], const int (&permv)[NT], int P) {
+    const int wave = threadIdx.x >> 6;
+    if (ROWS) {
+        if (entry_pos<true>(0, 3) >= P) {
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
-                acc[mi][ni] = *reinterpret_cast<const f32x4*>(c0p + ni * 16 * CSC_TILE_ROWS + 16 * mi);
-        for (int i = 0; i < d; ++i) {
-            const float ci = (float)sl->coefpar[i];
-            const float* gp = a.gram + ((size_t)sl->sup_atom[i] * CSC_TILE_COLS + lr) * GRAM_W +
-                              (prow0 - sl->sup_pos[i] + P - 1);
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        if (entry_pos<true>(mi, rg) >= P) acc[mi][ni][rg] = -INFINITY;
+        }
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi) {
-                    const f32x4 g = *reinterpret_cast<const f32x4u*>(gp + ni * 16 * GRAM_W + 16 * mi);
-                    acc[mi][ni] -= ci * g;
-                }
-        }
-    } else {
-        corr_tile_gemm(a.bank32t, sl->masks, (L + SLAB - 1) / SLAB, r32 + 64 * wave + lr + lq, slab, acc);
-        if (d == 0 && a.c0) {                                        // keep the signal's correlations for the levels below
-            float* c0p = a.c0 + ((size_t)s * CSC_TILE_COLS + lr) * CSC_TILE_ROWS + 64 * wave + 4 * lq;
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-                    *reinterpret_cast<f32x4*>(c0p + ni * 16 * CSC_TILE_ROWS + 16 * mi) = acc[mi][ni];
-            if (tid == 0) a.ynorm2[s] = rnorm2;
-        }
+                if (sl->perm[entry_col<true>(mi, ni)] < 0)           // wave-uniform
+                    acc[mi][ni] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        return;
     }
-
-    PROF_MARK(1);
-    int permv[NT];                                // atom of this lane's column in tile ni (-1 = padding)
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) permv[ni] = sl->perm[16 * ni + lr];
-    const int prow = 64 * wave + 4 * lq;          // + 16*mi + reg
-    const int rowK = prow * K;
-    // entries outside the (P x K) matrix never win: rows >= P (last row tile only) and padding columns
+    const int prow = entry_pos<false>(0, 0);
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
         if (64 * wave + 16 * mi + 15 >= P) {                         // wave-uniform
@@ -1005,23 +1049,87 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
                 for (int rg = 0; rg < 4; ++rg)
                     if (permv[ni] < 0) acc[mi][ni][rg] = -INFINITY;
         }
+}
 
-#ifdef CSC_PHASE_PROF
-    if (a.stagger_ticks == -7) {                  // development aid: GEMM only (CSC_STAGGER_US=-7 hack off by default)
-        float lm = -INFINITY;
+// multiply-by-zero suppression of the similarity disk of the placed atom (p_sel, k_sel), src/csc/mmp.py:214-218:
+// the atom's bit row of the similarity table is staged in LDS (aliasing the slab buffers), hit entries become
+// the value-0 marker.  Contains a barrier.
+template <bool ROWS>
+__device__ __forceinline__ void suppress_similar(const LevelArgs& a, NodeLds* sl, uint32_t* simrow, int p_sel, int k_sel,
+                                                 const int (&permv)[NT], f32x4 (&acc)[MT][NT], bool& lane_supp) {
+    const int tid = threadIdx.x;
+    const int W = a.W, W1 = a.W + 1, K = a.K, P = a.P;               // LDS rows padded by one word
+    const uint32_t* g = a.sim_bits + (size_t)k_sel * K * W;
+    __syncthreads();
+    for (int i = tid; i < K * W; i += WG) simrow[(i / W) * W1 + (i % W)] = g[i];
+    __syncthreads();
+    const int dp0 = entry_pos<ROWS>(0, 0) - p_sel + P - 1;           // + 16*mi + rg (MFMA) / + rg (rows): bit index
+    bool any = false;
+    if (ROWS) {
+        // this lane's four positions are four consecutive bits of the column's row: two words, one shift
+        const int w0 = min(dp0 >> 5, W - 1), w1 = min(w0 + 1, W - 1), sh = dp0 & 31;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni)
+            for (int ni = 0; ni < NT; ++ni) {
+                const uint32_t* row = simrow + max(sl->perm[entry_col<true>(mi, ni)], 0) * W1;   // wave-uniform
+                const uint64_t ww = ((uint64_t)row[w1] << 32) | row[w0];
+                const uint32_t bits = (uint32_t)(ww >> sh) & 15u;
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) lm = fmaxf(lm, acc[mi][ni][rg]);
-        if (lm == 12345.f) a.node_mse[0] = lm;
-        return;
+                for (int rg = 0; rg < 4; ++rg) {
+                    const bool hit = ((bits >> rg) & 1u) && acc[mi][ni][rg] > -INFINITY;
+                    acc[mi][ni][rg] = hit ? __uint_as_float(SUPP_BITS) : acc[mi][ni][rg];
+                    any |= hit;
+                }
+            }
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            const uint32_t* row = simrow + max(permv[ni], 0) * W1;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int dpi = dp0 + 16 * mi + rg;
+                    const bool hit = ((row[dpi >> 5] >> (dpi & 31)) & 1u) && acc[mi][ni][rg] > -INFINITY;
+                    acc[mi][ni][rg] = hit ? __uint_as_float(SUPP_BITS) : acc[mi][ni][rg];
+                    any |= hit;
+                }
+        }
     }
-#endif
-    // ---- children, one selection round per sibling -------------------------------------------------
+    lane_supp |= any;
+    if (__ballot(any) && (tid & 63) == 0) sl->any_supp = 1;
+}
+
+// Selection of the node's children + their least squares, on the correlations held in acc
+// (reference src/csc/mmp.py:210-231 and :61-70).  ROWS: row layout, filled from the tables; acc may hold the
+// fp16 first pass (approx): its band entries are re-evaluated from the fp32 tables, and a node that cannot be
+// settled that way reloads the full fp32 tables and carries on exactly.
+template <bool ROWS>
+__device__ __forceinline__ void select_children(const LevelArgs& a, NodeLds* sl, const double* r64, uint32_t* simrow,
+                                                size_t s, int j, int nch, float delta, bool approx, float band16,
+                                                f32x4 (&acc)[MT][NT]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15;
+    const int K = a.K, P = a.P, d = a.depth;
+    const int stride = a.ts.pw[d];
+    int permv[NT];                                // MFMA layout: atom of this lane's column in tile ni (-1 = padding)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) permv[ni] = ROWS ? 0 : sl->perm[16 * ni + lr];
+    mask_outside<ROWS>(sl, acc, permv, P);
+    if (tid == 0) sl->any_supp = 0;
+
     bool lane_supp = false;                       // this lane holds a suppressed (value 0) entry
-    for (int t = 0; t < nch; ++t) {
+    int applied = 0;                              // siblings whose similarity disk is already marked in acc
+    int t = 0;
+    while (t < nch) {
+        // multiply-by-zero suppression by the siblings selected so far (all of them again after a reload)
+        while (applied < t) {
+            suppress_similar<ROWS>(a, sl, simrow, sl->sib_pos[applied], sl->sib_atom[applied], permv, acc, lane_supp);
+            ++applied;
+        }
+        __syncthreads();
+        PROF_MARK(2);
         // (a) fp32 maximum.  Suppressed entries carry a quiet NaN, which fmaxf (maxNum) skips; their
         //     value 0 enters through lane_supp.
         float lmax = -INFINITY;
@@ -1033,19 +1141,20 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
                 for (int rg = 0; rg < 4; ++rg) lmax = fmaxf(lmax, acc[mi][ni][rg]);
         float bv = wave_max(lane_supp ? fmaxf(lmax, 0.f) : lmax);
         if (lane == 63) sl->wmax[wave] = bv;
-        if (tid == 0) sl->cand_cnt = 0;
+        if (tid == 0) { sl->cand_cnt = 0; sl->ex_cnt = 0; }
         __syncthreads();
-        const float m32 = fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
-        const float tau = m32 - delta;
-        const bool zero_band = (0.f >= tau);
-        // (b) every unsuppressed entry inside the fp32 error band of the maximum is a candidate
-        //     (NaN >= tau is false).  Only the few lanes whose own maximum reaches the band look at
-        //     their 144 entries: a dense, branch-free bit mask first (straight-line code with a branch
-        //     per entry made the instruction fetch, not the ALU, the cost of this phase), then a short
-        //     loop over the set bits.  Entry e = (4*mi + rg) * 9 + ni.
+        float m32 = fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
+        float tau = m32 - ((ROWS && approx) ? band16 : delta);
+        bool zero_band = (0.f >= tau);
+        bool fallback = ROWS && approx && zero_band;   // degenerate (value 0 of suppressed entries in the band)
+        // (b) every unsuppressed entry inside the error band of the maximum is a candidate (NaN >= tau is
+        //     false).  Only the few lanes whose own maximum reaches the band look at their 144 entries: a
+        //     dense, branch-free bit mask first (straight-line code with a branch per entry made the
+        //     instruction fetch, not the ALU, the cost of this phase), then a short loop over the set bits.
+        //     Entry e = (4*mi + rg) * 9 + ni.  After an fp16 first pass the band entries are re-evaluated in fp32.
         int Kb = K;                                // opaque copy: keeps index arithmetic out of the hot path
         asm volatile("" : "+v"(Kb));
-        if (lmax >= tau) {
+        if (lmax >= tau && !fallback) {
             uint32_t mk[5] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
@@ -1063,13 +1172,23 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
                     const int e = 32 * w + __builtin_ctz(mm);
                     mm &= mm - 1;
                     const int r = e / NT, ni = e - r * NT;
-                    const int slot = atomicAdd(&sl->cand_cnt, 1);
-                    if (slot < CAND_CAP)
-                        sl->cand_idx[slot] = rowK + (16 * (r >> 2) + (r & 3)) * Kb + sl->perm[16 * ni + lr];
+                    const int c = entry_col<ROWS>(r >> 2, ni), pp = entry_pos<ROWS>(r >> 2, r & 3);
+                    const int idx = pp * Kb + sl->perm[c];
+                    if (ROWS && approx) {
+                        float v = a.c0[((size_t)s * CSC_TILE_COLS + c) * CSC_TILE_ROWS + pp];
+                        for (int i = 0; i < d; ++i)
+                            v -= (float)sl->coefpar[i] *
+                                 a.gram[((size_t)sl->sup_atom[i] * CSC_TILE_COLS + c) * GRAM_W + pp - sl->sup_pos[i] + P - 1];
+                        const int slot = atomicAdd(&sl->ex_cnt, 1);
+                        if (slot < EX_CAP) { sl->ex_idx[slot] = idx; sl->ex_val[slot] = v; }
+                    } else {
+                        const int slot = atomicAdd(&sl->cand_cnt, 1);
+                        if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
+                    }
                 }
             }
         }
-        if (zero_band) {                           // degenerate: the value 0 of the suppressed entries competes
+        if (zero_band && !(ROWS && approx)) {    // degenerate: the value 0 of the suppressed entries competes
             int first_supp = 0x7fffffff;
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
@@ -1078,12 +1197,55 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
 #pragma unroll
                     for (int ni = 0; ni < NT; ++ni)
                         if (is_supp(acc[mi][ni][rg]))
-                            first_supp = min(first_supp, rowK + (16 * mi + rg) * Kb + permv[ni]);
+                            first_supp = min(first_supp, entry_pos<ROWS>(mi, rg) * Kb +
+                                                         (ROWS ? sl->perm[entry_col<true>(mi, ni)] : permv[ni]));
             first_supp = wave_min(first_supp);
             if (lane == 0) sl->wsupp[wave] = first_supp;
         }
         __syncthreads();
-        PROF_MARK(2);
+        PROF_MARK(3);
+        if (ROWS && approx) {
+            if (!fallback) {
+                // exact fp32 maximum over the re-evaluated entries (and 0 if suppressed entries exist), then
+                // the usual band around it
+                const int n = sl->ex_cnt;
+                if (n > EX_CAP || n == 0) {
+                    fallback = true;
+                } else {
+                    float mv = sl->any_supp ? 0.f : -INFINITY;
+                    for (int i = tid; i < n; i += WG) mv = fmaxf(mv, sl->ex_val[i]);
+                    mv = wave_max(mv);
+                    __syncthreads();               // wmax was read by every thread above
+                    if (lane == 63) sl->wmax[wave] = mv;
+                    __syncthreads();
+                    m32 = fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
+                    tau = m32 - delta;
+                    if (0.f >= tau) {
+                        fallback = true;           // the value 0 of suppressed entries competes: exact tables
+                    } else {
+                        for (int i = tid; i < n; i += WG)
+                            if (sl->ex_val[i] >= tau) {
+                                const int slot = atomicAdd(&sl->cand_cnt, 1);
+                                if (slot < CAND_CAP) sl->cand_idx[slot] = sl->ex_idx[i];
+                            }
+                        __syncthreads();
+                        if (sl->cand_cnt > CAND_CAP) fallback = true;
+                    }
+                }
+            }
+            if (fallback) {
+                // leave the fp16 pass for this node: full fp32 tables, suppression re-applied at the loop head
+                if (tid == 0 && a.stats) atomicAdd(&a.stats[3], 1);
+                approx = false;
+                __syncthreads();
+                fill_from_tables32(a, sl, s, d, P, acc);
+                mask_outside<ROWS>(sl, acc, permv, P);
+                lane_supp = false;
+                applied = 0;
+                continue;
+            }
+        }
+        PROF_MARK(4);
         const int ncand_raw = sl->cand_cnt;
         if (ncand_raw > CAND_CAP) {
             // overflow (never seen on real data): fall back to the fp32 arg-max, lowest index
@@ -1096,44 +1258,162 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
                     for (int ni = 0; ni < NT; ++ni) {
                         const float x = acc[mi][ni][rg];
                         const float e = is_supp(x) ? 0.f : x;
-                        if (e == m32) bi = min(bi, rowK + (16 * mi + rg) * Kb + permv[ni]);
+                        if (e == m32) bi = min(bi, entry_pos<ROWS>(mi, rg) * Kb +
+                                                   (ROWS ? sl->perm[entry_col<true>(mi, ni)] : permv[ni]));
                     }
             bi = wave_min(bi);
             if (lane == 0) sl->widx[wave] = bi;
         }
         rescore_and_choose(a, sl, r64, ncand_raw, zero_band);
-        PROF_MARK(3);
-        const int p_sel = sl->sup_pos[d], k_sel = sl->sup_atom[d];
+        PROF_MARK(5);
         const int jc = j + t * stride;                               // child's index in level d+1
         const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
-
+        if (tid == 0) { sl->sib_pos[t] = sl->sup_pos[d]; sl->sib_atom[t] = sl->sup_atom[d]; }
         child_solve_and_write(a, sl, r64, s, jc, cid);
-
-        PROF_MARK(6);
-        // ---- suppress the chosen atom's similarity disk for the next sibling ----------------------
-        if (t + 1 < nch) {
-            const int W = a.W, W1 = a.W + 1;                         // LDS rows padded by one word
-            const uint32_t* g = a.sim_bits + (size_t)k_sel * K * W;
-            for (int i = tid; i < K * W; i += WG) simrow[(i / W) * W1 + (i % W)] = g[i];
-            __syncthreads();
-            const int dp0 = prow - p_sel + P - 1;                    // + 16*mi + rg: bit index of this entry
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
-                const uint32_t* row = simrow + max(permv[ni], 0) * W1;
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const int dpi = dp0 + 16 * mi + rg;
-                        const bool hit = ((row[dpi >> 5] >> (dpi & 31)) & 1u) && acc[mi][ni][rg] > -INFINITY;
-                        acc[mi][ni][rg] = hit ? __uint_as_float(SUPP_BITS) : acc[mi][ni][rg];
-                        lane_supp |= hit;
-                    }
-            }
-        }
         __syncthreads();
-        PROF_MARK(7);
+        ++t;
     }
+}
+
+__device__ __forceinline__ int children_of(const LevelArgs& a, int j) {
+    const int d = a.depth, Fc = a.ts.F[d + 1], stride = a.ts.pw[d];
+    int nch = 0;
+    for (int r = 0; r < a.connections; ++r) {
+        if ((long long)j + (long long)r * stride < Fc) ++nch; else break;
+    }
+    return nch;
+}
+
+// ---- the level kernel: correlations of the node's residual on the matrix cores ---------------------------
+// Normal launch: one workgroup per node of the level.  Deferred launch (a.flags != nullptr): the table kernel
+// below has handled the level and flagged the nodes it could not; each workgroup looks at a.group consecutive
+// nodes and processes the flagged ones.
+__global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
+    extern __shared__ double lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int N = a.N, L = a.L, Lp = a.Lp, d = a.depth;
+
+    // ---- LDS carve-up ---------------------------------------------------------------------------
+    const int Npad = (N + 3) & ~3;
+    const int R32 = CSC_TILE_ROWS + Lp + 4;
+    float* slab = reinterpret_cast<float*>(lds_raw);                  // [2][SLABF]
+    uint32_t* simrow = reinterpret_cast<uint32_t*>(slab);             // aliases the slabs
+    double* r64 = lds_raw + SLABF;                                    // [Npad]   (2*SLABF floats = SLABF doubles)
+    float* r32 = reinterpret_cast<float*>(r64 + Npad);                // [R32]
+    NodeLds* sl = reinterpret_cast<NodeLds*>(r32 + ((R32 + 3) & ~3));
+
+    const int Fd = a.ts.F[d];
+    if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
+    if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
+
+    for (int q = 0; q < a.group; ++q) {
+        size_t s;
+        int j;
+        if (a.flags) {
+            const size_t nl = (size_t)blockIdx.x * a.group + q;
+            if (nl >= (size_t)a.S * Fd) break;
+            if (!a.flags[nl]) continue;                               // wave-uniform
+            s = nl / Fd;
+            j = (int)(nl - s * Fd);
+        } else {
+            node_of_block(Fd, s, j);
+        }
+        const int nch = children_of(a, j);
+
+        PROF_INIT(0);
+        const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
+        double rnorm2;
+        const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2);
+        PROF_MARK(0);
+        // ---- correlations on the matrix cores ----------------------------------------------------------
+        f32x4 acc[MT][NT];
+        corr_tile_gemm(a.bank32t, sl->masks, (L + SLAB - 1) / SLAB, r32 + 64 * wave + lr + lq, slab, acc);
+        if (d == 0 && a.c0) {                                        // keep the signal's correlations for the levels below
+            float* c0p = a.c0 + ((size_t)s * CSC_TILE_COLS + lr) * CSC_TILE_ROWS + 64 * wave + 4 * lq;
+            const float inv = rnorm2 > 0.0 ? (float)(1.0 / sqrt(rnorm2)) : 0.f;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    *reinterpret_cast<f32x4*>(c0p + ni * 16 * CSC_TILE_ROWS + 16 * mi) = acc[mi][ni];
+                    if (a.c0h)
+                        *reinterpret_cast<f16x4*>(a.c0h + (c0p - a.c0) + ni * 16 * CSC_TILE_ROWS + 16 * mi) =
+                            __builtin_convertvector(acc[mi][ni] * inv, f16x4);
+                }
+            if (tid == 0) a.ynorm2[s] = rnorm2;
+        }
+        PROF_MARK(1);
+#ifdef CSC_PHASE_PROF
+        if (a.stagger_ticks == -7) {              // development aid: GEMM only (CSC_GEMM_ONLY)
+            float lm = -INFINITY;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) lm = fmaxf(lm, acc[mi][ni][rg]);
+            if (lm == 12345.f) a.node_mse[0] = lm;
+            return;
+        }
+#endif
+        select_children<false>(a, sl, r64, simrow, s, j, nch, delta, false, 0.f, acc);
+        __syncthreads();
+        PROF_MARK(9);
+    }
+}
+
+// ---- the table kernel: levels >= 1 without a GEMM -----------------------------------------------------------
+// With r = y - sum_i c_i a_i(. - p_i):  C_r[p, k] = C_y[p, k] - sum_i c_i X[k_i][k][p - p_i], X = atom
+// cross-correlations (csc_gram_table), so a node's correlations are the signal's (kept by level 0) minus d table
+// slices, loaded straight into the registers the GEMM would have filled.  The fp32 error of that route scales
+// with ||y||, not ||r||: the candidate band is widened to 2^-14 ||y|| + 2^-20 sum |c_i|.
+// First pass in fp16 (half the bytes): C~ / ||y|| from the fp16 copies.  Its error is at most
+// eps16 = 2^-11 (1 + sum |c_i| / ||y||) in those units, so every entry that can be the fp32 maximum or lie in its
+// band is within 2 eps16 + delta of the approximate maximum; those few (mean ~10) are re-evaluated from the fp32
+// tables and the selection proceeds on exact fp32 values (select_children<true>).
+// A node whose residual has collapsed (||r|| < ||y|| / 64: the table error would swamp its correlations) is
+// flagged for the deferred launch of mmp_level_kernel, which multiplies its residual.
+__global__ __launch_bounds__(WG, 2) void mmp_level_table_kernel(const LevelArgs a) {
+    extern __shared__ double lds_raw[];
+    const int tid = threadIdx.x;
+    const int N = a.N, K = a.K, P = a.P, d = a.depth;
+    const int Npad = (N + 3) & ~3;
+    uint32_t* simrow = reinterpret_cast<uint32_t*>(lds_raw);          // [K][W + 1]
+    double* r64 = lds_raw + ((K * (a.W + 1) + 1) >> 1);               // [Npad]
+    NodeLds* sl = reinterpret_cast<NodeLds*>(r64 + Npad);
+
+    const int Fd = a.ts.F[d];
+    size_t s;
+    int j;
+    node_of_block(Fd, s, j);
+    const int nch = children_of(a, j);
+    if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
+
+    PROF_INIT(16);
+    const double* rin = a.resid_in + (s * Fd + j) * (size_t)a.NS;
+    double rnorm2;
+    node_prologue(a, sl, r64, nullptr, Npad, 0, rin, s, j, rnorm2);
+    PROF_MARK(0);
+    const double y2 = a.ynorm2[s];
+    const bool defer = !(y2 > 0.0 && rnorm2 * 4096.0 >= y2);
+    if (tid == 0) a.flags[s * Fd + j] = defer ? 1 : 0;
+    if (defer) return;
+
+    float csum = 0.f;
+    for (int i = 0; i < d; ++i) csum += fabsf((float)sl->coefpar[i]);
+    const float ynorm = (float)sqrt(y2);
+    const float delta = DELTA_REL * ynorm + 9.5367431640625e-07f * csum;
+    const bool approx = a.gram16 && y2 < 1e30 && y2 > 1e-30;
+    // 2 eps16 + delta, in units of ||y|| (2^-11 rounding of every fp16 operand, 2^-23 for the fp32 arithmetic)
+    const float band16 = 2.f * (4.8828125e-04f + 1.1920929e-07f) * (1.f + csum / ynorm) + delta / ynorm;
+
+    f32x4 acc[MT][NT];
+    if (approx) fill_from_tables16(a, sl, s, d, P, ynorm, acc);
+    else fill_from_tables32(a, sl, s, d, P, acc);
+    PROF_MARK(1);
+    select_children<true>(a, sl, r64, simrow, s, j, nch, delta, approx, band16, acc);
+    PROF_MARK(9);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1256,6 +1536,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled_kernel(const LevelArgs 
     double* r64 = lds_raw + SLABF;                                    // [Npad]
     float* r32 = reinterpret_cast<float*>(r64 + Npad);                // [R32]
     NodeLds* sl = reinterpret_cast<NodeLds*>(r32 + ((R32 + 3) & ~3));
+    PROF_INIT(0);
     TiledLds* tl2 = reinterpret_cast<TiledLds*>(sl + 1);
 
     const int Fd = a.ts.F[d], Fc = a.ts.F[d + 1];
@@ -1628,14 +1909,19 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
     TreeShape ts;
     if (make_shape(max_sparsity, connections, branches, &ts) < 0 || S <= 0 || N <= 0) return 0;
     size_t b = node_ws_bytes(S, N, max_sparsity, ts);
-    if (with_gram) b += (size_t)S * CSC_TILE_COLS * CSC_TILE_ROWS * sizeof(float) + (size_t)S * sizeof(double);
+    if (with_gram) {   // C_y in f32 and (scaled) f16, ||y||^2, one deferral flag per frontier node
+        int fmax = 1;
+        for (int d = 1; d < max_sparsity; ++d) fmax = ts.F[d] > fmax ? ts.F[d] : fmax;
+        b += (size_t)S * CSC_TILE_COLS * CSC_TILE_ROWS * (sizeof(float) + 2) + (size_t)S * sizeof(double) +
+             (((size_t)S * fmax + 7) & ~(size_t)7);
+    }
     return b;
 }
 
 size_t csc_gram_elems(int K, int L, int N) {
     const int P = N - L + 1;
     if (K <= 0 || K > CSC_TILE_COLS || P <= 0 || P > CSC_TILE_ROWS) return 0;
-    return (size_t)K * CSC_TILE_COLS * GRAM_W;
+    return 2 * (size_t)K * CSC_TILE_COLS * GRAM_W;                   // f32 table + two f16 copies
 }
 
 int csc_gram_table(const double* d_bank64, const float* d_bank32t, int K, int L, int N, float* d_gram,
@@ -1647,7 +1933,8 @@ int csc_gram_table(const double* d_bank64, const float* d_bank32t, int K, int L,
              CSC_TILE_ROWS, K, P);
     clear_stale_error();
     hipLaunchKernelGGL(gram_table_kernel, dim3(CSC_TILE_COLS, K), dim3(WG), (size_t)2 * L * sizeof(double),
-                       (hipStream_t)stream, d_bank64, bank_meta(d_bank32t, K, L), K, L, P, d_gram);
+                       (hipStream_t)stream, d_bank64, bank_meta(d_bank32t, K, L), K, L, P, d_gram,
+                       reinterpret_cast<_Float16*>(d_gram + (size_t)K * CSC_TILE_COLS * GRAM_W));
     return launch_status("gram_table_kernel");
 }
 
@@ -1694,9 +1981,15 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
 
     double* ws[2] = {static_cast<double*>(d_workspace), static_cast<double*>(d_workspace) + node_bytes / 16};
     float* c0 = gram ? reinterpret_cast<float*>(static_cast<char*>(d_workspace) + node_bytes) : nullptr;
-    double* ynorm2 = gram ? reinterpret_cast<double*>(static_cast<char*>(d_workspace) + node_bytes +
-                                                      (size_t)S * CSC_TILE_COLS * CSC_TILE_ROWS * sizeof(float))
-                          : nullptr;
+    const size_t cy = (size_t)S * CSC_TILE_COLS * CSC_TILE_ROWS;
+    _Float16* c0h = gram ? reinterpret_cast<_Float16*>(static_cast<char*>(d_workspace) + node_bytes + cy * 4) : nullptr;
+    double* ynorm2 = gram ? reinterpret_cast<double*>(static_cast<char*>(d_workspace) + node_bytes + cy * 6) : nullptr;
+    const bool fp16_pass = gram && !getenv("CSC_GRAM_FP32_ONLY");     // development / test switch
+    uint8_t* flags = gram ? reinterpret_cast<uint8_t*>(ynorm2 + S) : nullptr;
+    const size_t lds_table = (size_t)((K * (W + 1) + 1) / 2 + ceil4(N)) * 8 + sizeof(NodeLds);
+    const int group = 16;                                            // nodes per workgroup of a deferred launch
+    if (gram) hipFuncSetAttribute((const void*)mmp_level_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_table);
     hipStream_t st = (hipStream_t)stream;
     for (int d = 0; d < max_sparsity; ++d) {
         LevelArgs a;
@@ -1705,15 +1998,27 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         a.depth = d; a.Kmax = max_sparsity; a.connections = connections; a.NN = NN;
         a.NS = N + TRI(max_sparsity) + max_sparsity; a.stagger_ticks = stagger_ticks(); a.mode = mode;
         a.gram = gram ? d_gram : nullptr; a.c0 = c0; a.ynorm2 = ynorm2;
+        a.gram16 = fp16_pass ? reinterpret_cast<const _Float16*>(d_gram + (size_t)K * CSC_TILE_COLS * GRAM_W) : nullptr;
+        a.c0h = fp16_pass ? c0h : nullptr;
         a.resid_in = (d == 0) ? d_signals : ws[d & 1];
         a.resid_out = (d + 1 < max_sparsity) ? ws[(d + 1) & 1] : nullptr;
         a.node_pos = d_node_pos; a.node_atom = d_node_atom; a.node_mse = d_node_mse; a.node_coef = d_node_coef;
         a.stats = d_stats; a.ts = ts;
         const size_t grid = (size_t)S * ts.F[d];
         if (grid > 0x7fffffffULL) FAIL(-11, "batch too large for one launch (%zu workgroups)", grid);
+        a.flags = nullptr; a.group = 1; a.S = S;
         const int span = timer_begin(st, d);
-        if (tiled) hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
-        else hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
+        if (tiled) {
+            hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
+        } else if (gram && d >= 1 && d <= GRAM_MAX_DEPTH) {
+            // table kernel for the whole level, then the GEMM kernel for the nodes it flagged (usually none)
+            a.flags = flags;
+            hipLaunchKernelGGL(mmp_level_table_kernel, dim3((unsigned)grid), dim3(WG), lds_table, st, a);
+            a.group = group;
+            hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)((grid + group - 1) / group)), dim3(WG), lds, st, a);
+        } else {
+            hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
+        }
         timer_end(st, span);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) FAIL((int)e, "mmp_level_kernel launch failed at level %d: %s", d, hipGetErrorString(e));
@@ -1821,10 +2126,10 @@ int csc_timer_read(csc_timer* t, float* ms, int* tag, int n) {
 }
 
 #ifdef CSC_PHASE_PROF
-int csc_prof_read(unsigned long long* out16, int reset) {
+int csc_prof_read(unsigned long long* out32, int reset) {
     hipDeviceSynchronize();
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z); }
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z); }
     return 0;
 }
 #endif

@@ -73,7 +73,9 @@ int csc_tree_nodes(int max_sparsity, int connections, int branches, int* level_s
  * table slice per ancestor.  Exactness of the selection is kept by the fp64 re-score of every entry in
  * the (widened) fp32 error band.  Available when the whole correlation matrix fits one register tile:
  * K <= 144 and 1 <= N - L + 1 <= 256; csc_gram_elems returns 0 otherwise.
- *   d_gram [K][144][512] f32, column order of d_bank32t (csc_bank_pack must have run). */
+ *   d_gram: csc_gram_elems floats = [K][144][512] f32 followed by two fp16 copies of the same table
+ *   (first pass of the deeper levels at half the bytes; the entries in its error band are re-evaluated
+ *   from the f32 table), column order of d_bank32t (csc_bank_pack must have run). */
 size_t csc_gram_elems(int K, int L, int N);
 int csc_gram_table(const double* d_bank64, const float* d_bank32t, int K, int L, int N, float* d_gram,
                    void* stream);

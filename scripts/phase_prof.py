@@ -1,5 +1,5 @@
-"""Development aid: per-phase shader-clock shares of mmp_level_kernel (needs `make -C csc_amd/csrc prof`,
-run with CSC_HIP_LIB=csc_amd/csrc/libcsc_hip_prof.so)."""
+"""Development aid: per-phase shader-clock shares of the level kernels (needs `make -C csc_amd/csrc prof`,
+run with CSC_HIP_LIB=csc_amd/csrc/libcsc_hip_prof.so).  Clocks are thread 0's, summed over workgroups."""
 import ctypes as C, sys
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -8,17 +8,25 @@ from csc_amd import _lib
 dic = bench.canonical_dictionary()
 sig = bench.make_signals(dic, 0)
 bank = dic.device_bank()
+if "--mfma" in sys.argv:            # every level on the matrix cores (no table)
+    bank.use_gram = False
 d = torch.from_numpy(sig).cuda()
 out = bank.mmpdf_launch(d, 5, 3, 3, 0.8, want_coef=False)
 L = _lib.lib()
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 32)()
 L.csc_prof_read(buf, 1)
 bank.mmpdf_launch(d, 5, 3, 3, 0.8, want_coef=False, out=out)
+torch.cuda.synchronize()
 L.csc_prof_read(buf, 1)
 v = np.array(list(buf), dtype=np.float64)
-names = ["prologue", "gemm", "argmax+cands", "rescore+choose", "gram dots", "solve", "residual+write", "suppress/tail"]
-nodes = 3200 * 13
-tot = v[:8].sum()
-for n, x in zip(names, v):
-    print(f"{n:16s} {x / nodes:10.0f} clk/node  {100 * x / tot:5.1f} %")
-print("total", tot / nodes, "clk/node")
+names = ["prologue", "gemm / table fill", "suppress", "max + candidates", "fp16 band resolve", "rescore + choose",
+         "gram dots", "solve", "residual + write", "tail"]
+rows = (("mmp_level_kernel (all levels)", 0, 3200 * 13),) if "--mfma" in sys.argv else \
+    (("mmp_level_kernel (level 0)", 0, 3200), ("mmp_level_table_kernel (levels 1-4)", 16, 3200 * 12))
+for title, base, nodes in rows:
+    w = v[base:base + 10]
+    tot = w.sum()
+    print(title)
+    for n, x in zip(names, w):
+        print(f"  {n:18s} {x / nodes:10.0f} clk/node  {100 * x / max(tot, 1):5.1f} %")
+    print(f"  total {tot / nodes:.0f} clk/node")

@@ -31,7 +31,11 @@ def test_gram_table(bank, golden_bank):
     b = golden_bank["bank"]
     K, L = b.shape
     P = 738 - L + 1
-    g = bank.gram_table(738).cpu().numpy().reshape(K, 144, 512)
+    raw = bank.gram_table(738).cpu().numpy()
+    g = raw[:K * 144 * 512].reshape(K, 144, 512)
+    h = raw[K * 144 * 512:].view(np.float16).reshape(2, K, 144, 512)
+    assert np.array_equal(h[0], g.astype(np.float16))                  # fp16 copy, and the same shifted by one
+    assert np.array_equal(h[1][:, :, 1:], h[0][:, :, :-1]) and not h[1][:, :, 0].any()
     perm = bank.bank32t.cpu().numpy()[16 * 9 * 512:].view(np.int32)[:144]
     assert not g[:, perm < 0].any() and not g[:, :, 2 * P - 1:].any()
     rng = np.random.default_rng(0)
