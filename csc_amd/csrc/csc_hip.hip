@@ -37,13 +37,12 @@
 #define SLABF (NT * BLKF)              // floats of one slab of a 144-atom bank tile
 #define MAX_SLABS 64                   // L <= 2048
 #define META_INTS (CSC_TILE_COLS + MAX_SLABS)   // per bank tile: perm[144] + slab masks[64]
-#define CAND_CAP 64
+#define CAND_CAP 128
 #define SUPP_BITS 0x7fc00001u          // quiet-NaN payload marking a suppressed entry (value 0)
 #define KMAX CSC_MAX_SPARSITY
 #define TRI(n) ((n) * ((n) + 1) / 2)
 #define DELTA_REL 6.103515625e-05f      // 2^-14: fp32 candidate band, in units of ||residual||
 #define GRAM_W (2 * CSC_TILE_ROWS)     // shifts per (atom, column) row of the cross-correlation table
-#define EX_CAP 512                     // entries of the fp16 first pass that are re-evaluated in fp32
 #define GRAM_MAX_DEPTH 6               // a node at depth d streams (1 + d) x 147 KB; past ~7 slices the GEMM is cheaper
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -52,7 +51,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 8-byte access
 
 // Development aid (make prof): per-phase shader-clock totals of the level kernels, summed over workgroups
-// (slots 0-15: mmp_level_kernel, 16-31: mmp_level_table_kernel; scripts/phase_prof.py names them).
+// (slots 0-15: GEMM nodes, 16-31: table nodes; scripts/phase_prof.py names them).
 #ifdef CSC_PHASE_PROF
 __device__ unsigned long long g_prof[32];
 #define PROF_FIELDS unsigned long long prof_t; int prof_base;
@@ -87,14 +86,12 @@ struct LevelArgs {
     double* resid_out;        // [S][F[d+1]][NS] or nullptr (children are final leaves)
     int32_t* node_pos; int32_t* node_atom; double* node_mse; double* node_coef;
     int32_t* stats;
-    const float* gram;    // atom cross-correlation table [K][144][GRAM_W] f32 or nullptr (always the GEMM)
-    const _Float16* gram16;  // the same table in fp16, two copies ([2][K][144][GRAM_W]; copy 1 shifted by one
-                          // element so that every 4-element window starts dword-aligned), or nullptr
-    float* c0;            // [S][144][256] f32: correlations of the ORIGINAL signals, written by level 0
-    _Float16* c0h;        // [S][144][256] f16: the same divided by ||y|| (first-pass operand)
+    const _Float16* gram16;  // atom cross-correlation table in fp16, two copies ([2][K][144][GRAM_W]; copy 1 is
+                          // shifted by one element so that every 4-element window starts dword-aligned), or
+                          // nullptr (every level multiplies)
+    const float* xmax;    // max |table entry| = max_k ||a_k||^2 (scales the fp16 error bound)
+    _Float16* c0h;        // [S][144][256] f16: correlations of the ORIGINAL signals / ||y||, written by level 0
     double* ynorm2;       // [S] squared norm of the original signals, written by level 0
-    uint8_t* flags;       // [S][F[d]] table kernel -> deferred GEMM launch: 1 = this node still needs the GEMM
-    int group, S;         // deferred launch: nodes per workgroup; number of signals
     TreeShape ts;
 };
 
@@ -411,18 +408,17 @@ __global__ __launch_bounds__(WG) void sim_table_kernel(const double* __restrict_
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void gram_table_kernel(const double* __restrict__ bank64,
                                                         const int32_t* __restrict__ meta, int K, int L, int P,
-                                                        float* __restrict__ gram, _Float16* __restrict__ gram16) {
+                                                        _Float16* __restrict__ gram16, float* __restrict__ xmax) {
     extern __shared__ double sm[];
     double* a_sel = sm;            // [L]
     double* a_k = sm + L;          // [L]
     const int ksel = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
     const int k = meta[c];
-    float* row = gram + ((size_t)ksel * CSC_TILE_COLS + c) * GRAM_W;
-    // fp16 copies: h0[j] = X[j], h1[j] = X[j - 1] (so a 4-element window at an odd j starts dword-aligned in h1)
+    // two fp16 copies: h0[j] = X[j], h1[j] = X[j - 1] (so a 4-element window at an odd j starts dword-aligned in h1)
     _Float16* h0 = gram16 + ((size_t)ksel * CSC_TILE_COLS + c) * GRAM_W;
     _Float16* h1 = h0 + (size_t)K * CSC_TILE_COLS * GRAM_W;
     if (k < 0) {                                                     // padding column
-        for (int i = tid; i < GRAM_W; i += WG) { row[i] = 0.f; h0[i] = (_Float16)0.f; h1[i] = (_Float16)0.f; }
+        for (int i = tid; i < GRAM_W; i += WG) { h0[i] = (_Float16)0.f; h1[i] = (_Float16)0.f; }
         return;
     }
     for (int i = tid; i < L; i += WG) {
@@ -430,6 +426,7 @@ __global__ __launch_bounds__(WG) void gram_table_kernel(const double* __restrict
         a_k[i] = bank64[(size_t)k * L + i];
     }
     __syncthreads();
+    float big = 0.f;
     for (int dpi = tid; dpi < GRAM_W; dpi += WG) {
         double acc = 0.0;
         if (dpi < 2 * P - 1) {
@@ -437,11 +434,13 @@ __global__ __launch_bounds__(WG) void gram_table_kernel(const double* __restrict
             const int j0 = max(0, -dp), j1 = min(L, L - dp);
             for (int j = j0; j < j1; ++j) acc = fma(a_k[j], a_sel[j + dp], acc);
         }
-        row[dpi] = (float)acc;
         h0[dpi] = (_Float16)(float)acc;
         if (dpi + 1 < GRAM_W) h1[dpi + 1] = (_Float16)(float)acc;
         if (dpi == 0) h1[0] = (_Float16)0.f;
+        big = fmaxf(big, fabsf((float)acc));                          // NaN is skipped; Inf stays
     }
+    big = wave_max(big);
+    if ((tid & 63) == 63) atomicMax(reinterpret_cast<unsigned*>(xmax), __float_as_uint(big));   // big >= 0
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -635,10 +634,6 @@ struct NodeLds {
     int widx[WG / 64], wsupp[WG / 64];
     int cand_cnt, chosen, i32, bad, odd_slot;
     float m32;
-    int ex_cnt, any_supp;
-    int sib_pos[CSC_MAX_CONNECTIONS], sib_atom[CSC_MAX_CONNECTIONS];
-    int ex_idx[EX_CAP];            // fp16 first pass: flattened index and fp32 value of the entries in its band
-    float ex_val[EX_CAP];
     PROF_FIELDS
 };
 
@@ -908,9 +903,9 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
 
 // ---- the correlations of a node held in registers: two layouts -------------------------------------------
 // f32x4 acc[MT][NT] (144 values per lane) holds the (256 positions x 144 bank columns) correlation tile.
-//   MFMA layout (ROWS = false, mmp_level_kernel): what v_mfma_f32_16x16x4 leaves behind,
+//   MFMA layout (ROWS = false, GEMM nodes): what v_mfma_f32_16x16x4 leaves behind,
 //       position 64*wave + 16*mi + 4*(lane>>4) + rg, bank column 16*ni + (lane&15)
-//   row layout (ROWS = true, mmp_level_table_kernel): a wave instruction covers one whole bank column,
+//   row layout (ROWS = true, table nodes): a wave instruction covers one whole bank column,
 //       position 4*lane + rg, bank column 36*wave + 9*mi + ni
 //     so every table load is one contiguous kilobyte (the MFMA layout touches 16 rows of 64 bytes each).
 template <bool ROWS>
@@ -947,34 +942,7 @@ __device__ __forceinline__ void sub_cols(f32x4 (&acc)[NT], float ci, const f16x4
     for (int ni = 0; ni < NT; ++ni) acc[ni] -= ci * __builtin_convertvector(b[ni], f32x4);
 }
 
-// row layout from the tables: acc = C_y - sum_i c_i X_i
-__device__ __forceinline__ void fill_from_tables32(const LevelArgs& a, const NodeLds* sl, size_t s, int d, int P,
-                                                   f32x4 (&acc)[MT][NT]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* c0p = a.c0 + ((size_t)s * CSC_TILE_COLS + 36 * wave) * CSC_TILE_ROWS + 4 * lane;
-    const float* gbase = a.gram + (size_t)36 * wave * GRAM_W + (4 * lane + P - 1);
-    const size_t astride = (size_t)CSC_TILE_COLS * GRAM_W;
-    f32x4 A[NT], B[NT];
-    const float* gp = gbase + sl->sup_atom[0] * astride - sl->sup_pos[0];     // d >= 1
-    load_cols<f32x4u>(gp, 0, A);
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni)
-            acc[mi][ni] = *reinterpret_cast<const f32x4*>(c0p + (NT * mi + ni) * CSC_TILE_ROWS);
-    for (int i = 0; i < d; ++i) {
-        const float ci = (float)sl->coefpar[i];
-        const int in = min(i + 1, d - 1);                            // the last slice is fetched again (one batch)
-        const float* gpn = gbase + sl->sup_atom[in] * astride - sl->sup_pos[in];
-        load_cols<f32x4u>(gp, 1, B);  pin(A); sub_cols(acc[0], ci, A);
-        load_cols<f32x4u>(gp, 2, A);  pin(B); sub_cols(acc[1], ci, B);
-        load_cols<f32x4u>(gp, 3, B);  pin(A); sub_cols(acc[2], ci, A);
-        load_cols<f32x4u>(gpn, 0, A); pin(B); sub_cols(acc[3], ci, B);
-        gp = gpn;
-    }
-}
-
-// the same from the fp16 copies, in units of ||y||: acc = C_y/||y|| - sum_i (c_i/||y||) X16_i
+// row layout from the fp16 tables, in units of ||y||: acc = C_y/||y|| - sum_i (c_i/||y||) X_i
 __device__ __forceinline__ void fill_from_tables16(const LevelArgs& a, const NodeLds* sl, size_t s, int d, int P,
                                                    float ynorm, f32x4 (&acc)[MT][NT]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1098,17 +1066,16 @@ __device__ __forceinline__ void suppress_similar(const LevelArgs& a, NodeLds* sl
         }
     }
     lane_supp |= any;
-    if (__ballot(any) && (tid & 63) == 0) sl->any_supp = 1;
 }
 
 // Selection of the node's children + their least squares, on the correlations held in acc
-// (reference src/csc/mmp.py:210-231 and :61-70).  ROWS: row layout, filled from the tables; acc may hold the
-// fp16 first pass (approx): its band entries are re-evaluated from the fp32 tables, and a node that cannot be
-// settled that way reloads the full fp32 tables and carries on exactly.
+// (reference src/csc/mmp.py:210-231 and :61-70).  `band` is the width below the maximum inside which an entry
+// may be the float64 maximum: every such entry is re-scored in float64.  ROWS: row layout, acc holds the fp16
+// table values (wide band); returns false if the node cannot be settled that way (the caller then multiplies
+// its residual after all and repeats the node from the start, with identical results).
 template <bool ROWS>
-__device__ __forceinline__ void select_children(const LevelArgs& a, NodeLds* sl, const double* r64, uint32_t* simrow,
-                                                size_t s, int j, int nch, float delta, bool approx, float band16,
-                                                f32x4 (&acc)[MT][NT]) {
+__device__ __forceinline__ bool select_children(const LevelArgs& a, NodeLds* sl, const double* r64, uint32_t* simrow,
+                                                size_t s, int j, int nch, float band, f32x4 (&acc)[MT][NT]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15;
     const int K = a.K, P = a.P, d = a.depth;
@@ -1117,17 +1084,11 @@ __device__ __forceinline__ void select_children(const LevelArgs& a, NodeLds* sl,
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) permv[ni] = ROWS ? 0 : sl->perm[16 * ni + lr];
     mask_outside<ROWS>(sl, acc, permv, P);
-    if (tid == 0) sl->any_supp = 0;
 
     bool lane_supp = false;                       // this lane holds a suppressed (value 0) entry
-    int applied = 0;                              // siblings whose similarity disk is already marked in acc
-    int t = 0;
-    while (t < nch) {
-        // multiply-by-zero suppression by the siblings selected so far (all of them again after a reload)
-        while (applied < t) {
-            suppress_similar<ROWS>(a, sl, simrow, sl->sib_pos[applied], sl->sib_atom[applied], permv, acc, lane_supp);
-            ++applied;
-        }
+    for (int t = 0; t < nch; ++t) {
+        // multiply-by-zero suppression by the sibling selected last
+        if (t > 0) suppress_similar<ROWS>(a, sl, simrow, sl->sup_pos[d], sl->sup_atom[d], permv, acc, lane_supp);
         __syncthreads();
         PROF_MARK(2);
         // (a) fp32 maximum.  Suppressed entries carry a quiet NaN, which fmaxf (maxNum) skips; their
@@ -1141,20 +1102,20 @@ __device__ __forceinline__ void select_children(const LevelArgs& a, NodeLds* sl,
                 for (int rg = 0; rg < 4; ++rg) lmax = fmaxf(lmax, acc[mi][ni][rg]);
         float bv = wave_max(lane_supp ? fmaxf(lmax, 0.f) : lmax);
         if (lane == 63) sl->wmax[wave] = bv;
-        if (tid == 0) { sl->cand_cnt = 0; sl->ex_cnt = 0; }
+        if (tid == 0) sl->cand_cnt = 0;
         __syncthreads();
-        float m32 = fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
-        float tau = m32 - ((ROWS && approx) ? band16 : delta);
-        bool zero_band = (0.f >= tau);
-        bool fallback = ROWS && approx && zero_band;   // degenerate (value 0 of suppressed entries in the band)
+        const float m32 = fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
+        const float tau = m32 - band;
+        const bool zero_band = (0.f >= tau);
+        if (ROWS && zero_band) return false;       // the value 0 of suppressed entries may compete: exact path
         // (b) every unsuppressed entry inside the error band of the maximum is a candidate (NaN >= tau is
         //     false).  Only the few lanes whose own maximum reaches the band look at their 144 entries: a
         //     dense, branch-free bit mask first (straight-line code with a branch per entry made the
         //     instruction fetch, not the ALU, the cost of this phase), then a short loop over the set bits.
-        //     Entry e = (4*mi + rg) * 9 + ni.  After an fp16 first pass the band entries are re-evaluated in fp32.
+        //     Entry e = (4*mi + rg) * 9 + ni.
         int Kb = K;                                // opaque copy: keeps index arithmetic out of the hot path
         asm volatile("" : "+v"(Kb));
-        if (lmax >= tau && !fallback) {
+        if (lmax >= tau) {
             uint32_t mk[5] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
@@ -1172,23 +1133,13 @@ __device__ __forceinline__ void select_children(const LevelArgs& a, NodeLds* sl,
                     const int e = 32 * w + __builtin_ctz(mm);
                     mm &= mm - 1;
                     const int r = e / NT, ni = e - r * NT;
-                    const int c = entry_col<ROWS>(r >> 2, ni), pp = entry_pos<ROWS>(r >> 2, r & 3);
-                    const int idx = pp * Kb + sl->perm[c];
-                    if (ROWS && approx) {
-                        float v = a.c0[((size_t)s * CSC_TILE_COLS + c) * CSC_TILE_ROWS + pp];
-                        for (int i = 0; i < d; ++i)
-                            v -= (float)sl->coefpar[i] *
-                                 a.gram[((size_t)sl->sup_atom[i] * CSC_TILE_COLS + c) * GRAM_W + pp - sl->sup_pos[i] + P - 1];
-                        const int slot = atomicAdd(&sl->ex_cnt, 1);
-                        if (slot < EX_CAP) { sl->ex_idx[slot] = idx; sl->ex_val[slot] = v; }
-                    } else {
-                        const int slot = atomicAdd(&sl->cand_cnt, 1);
-                        if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
-                    }
+                    const int idx = entry_pos<ROWS>(r >> 2, r & 3) * Kb + sl->perm[entry_col<ROWS>(r >> 2, ni)];
+                    const int slot = atomicAdd(&sl->cand_cnt, 1);
+                    if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
                 }
             }
         }
-        if (zero_band && !(ROWS && approx)) {    // degenerate: the value 0 of the suppressed entries competes
+        if (!ROWS && zero_band) {                  // degenerate: the value 0 of the suppressed entries competes
             int first_supp = 0x7fffffff;
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
@@ -1197,57 +1148,15 @@ __device__ __forceinline__ void select_children(const LevelArgs& a, NodeLds* sl,
 #pragma unroll
                     for (int ni = 0; ni < NT; ++ni)
                         if (is_supp(acc[mi][ni][rg]))
-                            first_supp = min(first_supp, entry_pos<ROWS>(mi, rg) * Kb +
-                                                         (ROWS ? sl->perm[entry_col<true>(mi, ni)] : permv[ni]));
+                            first_supp = min(first_supp, entry_pos<false>(mi, rg) * Kb + permv[ni]);
             first_supp = wave_min(first_supp);
             if (lane == 0) sl->wsupp[wave] = first_supp;
         }
         __syncthreads();
         PROF_MARK(3);
-        if (ROWS && approx) {
-            if (!fallback) {
-                // exact fp32 maximum over the re-evaluated entries (and 0 if suppressed entries exist), then
-                // the usual band around it
-                const int n = sl->ex_cnt;
-                if (n > EX_CAP || n == 0) {
-                    fallback = true;
-                } else {
-                    float mv = sl->any_supp ? 0.f : -INFINITY;
-                    for (int i = tid; i < n; i += WG) mv = fmaxf(mv, sl->ex_val[i]);
-                    mv = wave_max(mv);
-                    __syncthreads();               // wmax was read by every thread above
-                    if (lane == 63) sl->wmax[wave] = mv;
-                    __syncthreads();
-                    m32 = fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
-                    tau = m32 - delta;
-                    if (0.f >= tau) {
-                        fallback = true;           // the value 0 of suppressed entries competes: exact tables
-                    } else {
-                        for (int i = tid; i < n; i += WG)
-                            if (sl->ex_val[i] >= tau) {
-                                const int slot = atomicAdd(&sl->cand_cnt, 1);
-                                if (slot < CAND_CAP) sl->cand_idx[slot] = sl->ex_idx[i];
-                            }
-                        __syncthreads();
-                        if (sl->cand_cnt > CAND_CAP) fallback = true;
-                    }
-                }
-            }
-            if (fallback) {
-                // leave the fp16 pass for this node: full fp32 tables, suppression re-applied at the loop head
-                if (tid == 0 && a.stats) atomicAdd(&a.stats[3], 1);
-                approx = false;
-                __syncthreads();
-                fill_from_tables32(a, sl, s, d, P, acc);
-                mask_outside<ROWS>(sl, acc, permv, P);
-                lane_supp = false;
-                applied = 0;
-                continue;
-            }
-        }
-        PROF_MARK(4);
         const int ncand_raw = sl->cand_cnt;
-        if (ncand_raw > CAND_CAP) {
+        if (ROWS && ncand_raw > CAND_CAP) return false;
+        if (!ROWS && ncand_raw > CAND_CAP) {
             // overflow (never seen on real data): fall back to the fp32 arg-max, lowest index
             int bi = 0x7fffffff;
 #pragma unroll
@@ -1258,8 +1167,7 @@ __device__ __forceinline__ void select_children(const LevelArgs& a, NodeLds* sl,
                     for (int ni = 0; ni < NT; ++ni) {
                         const float x = acc[mi][ni][rg];
                         const float e = is_supp(x) ? 0.f : x;
-                        if (e == m32) bi = min(bi, entry_pos<ROWS>(mi, rg) * Kb +
-                                                   (ROWS ? sl->perm[entry_col<true>(mi, ni)] : permv[ni]));
+                        if (e == m32) bi = min(bi, entry_pos<false>(mi, rg) * Kb + permv[ni]);
                     }
             bi = wave_min(bi);
             if (lane == 0) sl->widx[wave] = bi;
@@ -1268,11 +1176,10 @@ __device__ __forceinline__ void select_children(const LevelArgs& a, NodeLds* sl,
         PROF_MARK(5);
         const int jc = j + t * stride;                               // child's index in level d+1
         const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
-        if (tid == 0) { sl->sib_pos[t] = sl->sup_pos[d]; sl->sib_atom[t] = sl->sup_atom[d]; }
         child_solve_and_write(a, sl, r64, s, jc, cid);
         __syncthreads();
-        ++t;
     }
+    return true;
 }
 
 __device__ __forceinline__ int children_of(const LevelArgs& a, int j) {
@@ -1284,10 +1191,20 @@ __device__ __forceinline__ int children_of(const LevelArgs& a, int j) {
     return nch;
 }
 
-// ---- the level kernel: correlations of the node's residual on the matrix cores ---------------------------
-// Normal launch: one workgroup per node of the level.  Deferred launch (a.flags != nullptr): the table kernel
-// below has handled the level and flagged the nodes it could not; each workgroup looks at a.group consecutive
-// nodes and processes the flagged ones.
+// ---- the level kernel ---------------------------------------------------------------------------------------
+// One workgroup per node of the level.  TABLES = false: the correlations of the node's residual are multiplied on
+// the matrix cores (level 0, dictionaries without a table, very deep levels).
+//
+// TABLES = true (levels >= 1): with r = y - sum_i c_i a_i(. - p_i),
+//     C_r[p, k] = C_y[p, k] - sum_i c_i X[k_i][k][p - p_i],   X = atom cross-correlations (csc_gram_table),
+// so a node's correlations are the signal's (kept by level 0) minus d table slices.  Both operands are held in
+// fp16 (C_y / ||y||, and X): the node streams (1 + d) x 74 KB instead of multiplying, and what it gets is only a
+// FILTER: every entry within twice the fp16 error bound of the computed maximum (a handful, rarely a few
+// dozen) is re-scored in float64 against the residual, exactly as the GEMM path re-scores its fp32 band, so the
+// selection is the float64 arg-max either way.  A node this cannot settle multiplies after all, in the same
+// workgroup: a collapsed residual (||r|| < ||y|| / 64, the error bound would swamp its correlations), more than
+// CAND_CAP entries in the band, the value 0 of suppressed entries inside the band, NaN / Inf / extreme scales.
+template <bool TABLES>
 __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     extern __shared__ double lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1304,115 +1221,85 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     NodeLds* sl = reinterpret_cast<NodeLds*>(r32 + ((R32 + 3) & ~3));
 
     const int Fd = a.ts.F[d];
-    if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
-    if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
-
-    for (int q = 0; q < a.group; ++q) {
-        size_t s;
-        int j;
-        if (a.flags) {
-            const size_t nl = (size_t)blockIdx.x * a.group + q;
-            if (nl >= (size_t)a.S * Fd) break;
-            if (!a.flags[nl]) continue;                               // wave-uniform
-            s = nl / Fd;
-            j = (int)(nl - s * Fd);
-        } else {
-            node_of_block(Fd, s, j);
-        }
-        const int nch = children_of(a, j);
-
-        PROF_INIT(0);
-        const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
-        double rnorm2;
-        const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2);
-        PROF_MARK(0);
-        // ---- correlations on the matrix cores ----------------------------------------------------------
-        f32x4 acc[MT][NT];
-        corr_tile_gemm(a.bank32t, sl->masks, (L + SLAB - 1) / SLAB, r32 + 64 * wave + lr + lq, slab, acc);
-        if (d == 0 && a.c0) {                                        // keep the signal's correlations for the levels below
-            float* c0p = a.c0 + ((size_t)s * CSC_TILE_COLS + lr) * CSC_TILE_ROWS + 64 * wave + 4 * lq;
-            const float inv = rnorm2 > 0.0 ? (float)(1.0 / sqrt(rnorm2)) : 0.f;
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi) {
-                    *reinterpret_cast<f32x4*>(c0p + ni * 16 * CSC_TILE_ROWS + 16 * mi) = acc[mi][ni];
-                    if (a.c0h)
-                        *reinterpret_cast<f16x4*>(a.c0h + (c0p - a.c0) + ni * 16 * CSC_TILE_ROWS + 16 * mi) =
-                            __builtin_convertvector(acc[mi][ni] * inv, f16x4);
-                }
-            if (tid == 0) a.ynorm2[s] = rnorm2;
-        }
-        PROF_MARK(1);
-#ifdef CSC_PHASE_PROF
-        if (a.stagger_ticks == -7) {              // development aid: GEMM only (CSC_GEMM_ONLY)
-            float lm = -INFINITY;
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) lm = fmaxf(lm, acc[mi][ni][rg]);
-            if (lm == 12345.f) a.node_mse[0] = lm;
-            return;
-        }
-#endif
-        select_children<false>(a, sl, r64, simrow, s, j, nch, delta, false, 0.f, acc);
-        __syncthreads();
-        PROF_MARK(9);
-    }
-}
-
-// ---- the table kernel: levels >= 1 without a GEMM -----------------------------------------------------------
-// With r = y - sum_i c_i a_i(. - p_i):  C_r[p, k] = C_y[p, k] - sum_i c_i X[k_i][k][p - p_i], X = atom
-// cross-correlations (csc_gram_table), so a node's correlations are the signal's (kept by level 0) minus d table
-// slices, loaded straight into the registers the GEMM would have filled.  The fp32 error of that route scales
-// with ||y||, not ||r||: the candidate band is widened to 2^-14 ||y|| + 2^-20 sum |c_i|.
-// First pass in fp16 (half the bytes): C~ / ||y|| from the fp16 copies.  Its error is at most
-// eps16 = 2^-11 (1 + sum |c_i| / ||y||) in those units, so every entry that can be the fp32 maximum or lie in its
-// band is within 2 eps16 + delta of the approximate maximum; those few (mean ~10) are re-evaluated from the fp32
-// tables and the selection proceeds on exact fp32 values (select_children<true>).
-// A node whose residual has collapsed (||r|| < ||y|| / 64: the table error would swamp its correlations) is
-// flagged for the deferred launch of mmp_level_kernel, which multiplies its residual.
-__global__ __launch_bounds__(WG, 2) void mmp_level_table_kernel(const LevelArgs a) {
-    extern __shared__ double lds_raw[];
-    const int tid = threadIdx.x;
-    const int N = a.N, K = a.K, P = a.P, d = a.depth;
-    const int Npad = (N + 3) & ~3;
-    uint32_t* simrow = reinterpret_cast<uint32_t*>(lds_raw);          // [K][W + 1]
-    double* r64 = lds_raw + ((K * (a.W + 1) + 1) >> 1);               // [Npad]
-    NodeLds* sl = reinterpret_cast<NodeLds*>(r64 + Npad);
-
-    const int Fd = a.ts.F[d];
     size_t s;
     int j;
     node_of_block(Fd, s, j);
     const int nch = children_of(a, j);
+    if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
     if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
 
-    PROF_INIT(16);
-    const double* rin = a.resid_in + (s * Fd + j) * (size_t)a.NS;
+    PROF_INIT(TABLES ? 16 : 0);
+    const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
     double rnorm2;
-    node_prologue(a, sl, r64, nullptr, Npad, 0, rin, s, j, rnorm2);
+    const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2);
     PROF_MARK(0);
-    const double y2 = a.ynorm2[s];
-    const bool defer = !(y2 > 0.0 && rnorm2 * 4096.0 >= y2);
-    if (tid == 0) a.flags[s * Fd + j] = defer ? 1 : 0;
-    if (defer) return;
-
-    float csum = 0.f;
-    for (int i = 0; i < d; ++i) csum += fabsf((float)sl->coefpar[i]);
-    const float ynorm = (float)sqrt(y2);
-    const float delta = DELTA_REL * ynorm + 9.5367431640625e-07f * csum;
-    const bool approx = a.gram16 && y2 < 1e30 && y2 > 1e-30;
-    // 2 eps16 + delta, in units of ||y|| (2^-11 rounding of every fp16 operand, 2^-23 for the fp32 arithmetic)
-    const float band16 = 2.f * (4.8828125e-04f + 1.1920929e-07f) * (1.f + csum / ynorm) + delta / ynorm;
-
     f32x4 acc[MT][NT];
-    if (approx) fill_from_tables16(a, sl, s, d, P, ynorm, acc);
-    else fill_from_tables32(a, sl, s, d, P, acc);
+    if (TABLES) {
+        const double y2 = a.ynorm2[s];
+        const float xm = *a.xmax;
+        if (y2 > 1e-30 && y2 < 1e30 && rnorm2 * 4096.0 >= y2 && xm > 1e-6f && xm < 1e4f) {
+            float csum = 0.f;
+            for (int i = 0; i < d; ++i) csum += fabsf((float)sl->coefpar[i]);
+            const float ynorm = (float)sqrt(y2);
+            // Error of an entry of acc, in units of ||y||: every fp16 operand is rounded by at most 2^-11
+            // relative (2^-25 absolute when subnormal), |C_y| <= ||y|| sqrt(xm), |X| <= xm; the level-0 GEMM and
+            // the fp32 arithmetic here add 2^-14 and (d + 1) 2^-23 of the same magnitudes.  An entry that can
+            // be the float64 maximum lies within twice that of the computed maximum.
+            const float mag = sqrtf(xm) + xm * csum / ynorm;
+            const float eps = (4.8828125e-04f + DELTA_REL + 1e-6f) * mag + 5.9604645e-08f * (1.f + csum / ynorm);
+            fill_from_tables16(a, sl, s, d, a.P, ynorm, acc);
+            PROF_MARK(1);
+            if (select_children<true>(a, sl, r64, simrow, s, j, nch, 2.f * eps, acc)) {
+                PROF_MARK(9);
+                return;
+            }
+            if (tid == 0 && a.stats) atomicAdd(&a.stats[3], 1);
+        }
+        PROF_INIT(0);                                                // what follows counts as the GEMM kernel's
+    }
+    // ---- correlations on the matrix cores ----------------------------------------------------------
+    corr_tile_gemm(a.bank32t, sl->masks, (L + SLAB - 1) / SLAB, r32 + 64 * wave + lr + lq, slab, acc);
+    if (!TABLES && d == 0 && a.c0h) {
+        // keep the signal's correlations, divided by ||y||, in fp16 for the levels below.  Each wave turns
+        // its (64 positions x 16 columns) pieces through LDS so that a store instruction writes eight whole
+        // 128-byte lines (straight from the MFMA layout it would write 16 x 32-byte fragments).
+        __syncthreads();                                             // every wave is done with the slab buffers
+        _Float16* tp = reinterpret_cast<_Float16*>(slab) + wave * (16 * 72);          // [16 columns][64 + 8]
+        const float inv = rnorm2 > 0.0 ? (float)(1.0 / sqrt(rnorm2)) : 0.f;
+        _Float16* dst = a.c0h + (size_t)s * CSC_TILE_COLS * CSC_TILE_ROWS + 64 * wave + 8 * (lane & 7);
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+                *reinterpret_cast<f16x4*>(tp + lr * 72 + 16 * mi + 4 * lq) =
+                    __builtin_convertvector(acc[mi][ni] * inv, f16x4);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int col = (lane >> 3) + 8 * h;
+                const uint4 v = *reinterpret_cast<const uint4*>(tp + col * 72 + 8 * (lane & 7));
+                *reinterpret_cast<uint4*>(dst + (size_t)(16 * ni + col) * CSC_TILE_ROWS) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (tid == 0) a.ynorm2[s] = rnorm2;
+    }
     PROF_MARK(1);
-    select_children<true>(a, sl, r64, simrow, s, j, nch, delta, approx, band16, acc);
+#ifdef CSC_PHASE_PROF
+    if (a.stagger_ticks == -7) {              // development aid: GEMM only (CSC_GEMM_ONLY)
+        float lm = -INFINITY;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) lm = fmaxf(lm, acc[mi][ni][rg]);
+        if (lm == 12345.f) a.node_mse[0] = lm;
+        return;
+    }
+#endif
+    select_children<false>(a, sl, r64, simrow, s, j, nch, delta, acc);
+    __syncthreads();
     PROF_MARK(9);
 }
 
@@ -1909,19 +1796,18 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
     TreeShape ts;
     if (make_shape(max_sparsity, connections, branches, &ts) < 0 || S <= 0 || N <= 0) return 0;
     size_t b = node_ws_bytes(S, N, max_sparsity, ts);
-    if (with_gram) {   // C_y in f32 and (scaled) f16, ||y||^2, one deferral flag per frontier node
-        int fmax = 1;
-        for (int d = 1; d < max_sparsity; ++d) fmax = ts.F[d] > fmax ? ts.F[d] : fmax;
-        b += (size_t)S * CSC_TILE_COLS * CSC_TILE_ROWS * (sizeof(float) + 2) + (size_t)S * sizeof(double) +
-             (((size_t)S * fmax + 7) & ~(size_t)7);
+    if (with_gram) {   // C_y / ||y|| in f16, ||y||^2
+        b += (size_t)S * CSC_TILE_COLS * CSC_TILE_ROWS * 2 + (size_t)S * sizeof(double);
     }
     return b;
 }
 
+static size_t gram_halves(int K) { return 2 * (size_t)K * CSC_TILE_COLS * GRAM_W; }    // two fp16 copies
+
 size_t csc_gram_elems(int K, int L, int N) {
     const int P = N - L + 1;
     if (K <= 0 || K > CSC_TILE_COLS || P <= 0 || P > CSC_TILE_ROWS) return 0;
-    return 2 * (size_t)K * CSC_TILE_COLS * GRAM_W;                   // f32 table + two f16 copies
+    return gram_halves(K) / 2 + 16;                                  // in floats: the copies + max |entry| (+ spare)
 }
 
 int csc_gram_table(const double* d_bank64, const float* d_bank32t, int K, int L, int N, float* d_gram,
@@ -1932,9 +1818,12 @@ int csc_gram_table(const double* d_bank64, const float* d_bank32t, int K, int L,
         FAIL(-9, "csc_gram_table: needs K <= %d and 1 <= P <= %d (got K = %d, P = %d)", CSC_TILE_COLS,
              CSC_TILE_ROWS, K, P);
     clear_stale_error();
+    float* xmax = d_gram + gram_halves(K) / 2;
+    if (hipMemsetAsync(xmax, 0, 16 * sizeof(float), (hipStream_t)stream) != hipSuccess)
+        FAIL(-1, "csc_gram_table: hipMemsetAsync failed");
     hipLaunchKernelGGL(gram_table_kernel, dim3(CSC_TILE_COLS, K), dim3(WG), (size_t)2 * L * sizeof(double),
-                       (hipStream_t)stream, d_bank64, bank_meta(d_bank32t, K, L), K, L, P, d_gram,
-                       reinterpret_cast<_Float16*>(d_gram + (size_t)K * CSC_TILE_COLS * GRAM_W));
+                       (hipStream_t)stream, d_bank64, bank_meta(d_bank32t, K, L), K, L, P,
+                       reinterpret_cast<_Float16*>(d_gram), xmax);
     return launch_status("gram_table_kernel");
 }
 
@@ -1976,20 +1865,15 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
     if (lds > 150 * 1024) FAIL(-8, "signal too long for the LDS-resident node kernel (%zu B)", lds);
     if (!tiled && (size_t)K * (W + 1) * 4 > 2 * SLABF * 4) FAIL(-8, "similarity row does not fit the slab buffer");
     clear_stale_error();
-    hipFuncSetAttribute(tiled ? (const void*)mmp_level_tiled_kernel : (const void*)mmp_level_kernel,
+    hipFuncSetAttribute(tiled ? (const void*)mmp_level_tiled_kernel : (const void*)mmp_level_kernel<false>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 
     double* ws[2] = {static_cast<double*>(d_workspace), static_cast<double*>(d_workspace) + node_bytes / 16};
-    float* c0 = gram ? reinterpret_cast<float*>(static_cast<char*>(d_workspace) + node_bytes) : nullptr;
     const size_t cy = (size_t)S * CSC_TILE_COLS * CSC_TILE_ROWS;
-    _Float16* c0h = gram ? reinterpret_cast<_Float16*>(static_cast<char*>(d_workspace) + node_bytes + cy * 4) : nullptr;
-    double* ynorm2 = gram ? reinterpret_cast<double*>(static_cast<char*>(d_workspace) + node_bytes + cy * 6) : nullptr;
-    const bool fp16_pass = gram && !getenv("CSC_GRAM_FP32_ONLY");     // development / test switch
-    uint8_t* flags = gram ? reinterpret_cast<uint8_t*>(ynorm2 + S) : nullptr;
-    const size_t lds_table = (size_t)((K * (W + 1) + 1) / 2 + ceil4(N)) * 8 + sizeof(NodeLds);
-    const int group = 16;                                            // nodes per workgroup of a deferred launch
-    if (gram) hipFuncSetAttribute((const void*)mmp_level_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds_table);
+    _Float16* c0h = gram ? reinterpret_cast<_Float16*>(static_cast<char*>(d_workspace) + node_bytes) : nullptr;
+    double* ynorm2 = gram ? reinterpret_cast<double*>(static_cast<char*>(d_workspace) + node_bytes + cy * 2) : nullptr;
+    if (gram) hipFuncSetAttribute((const void*)mmp_level_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
     hipStream_t st = (hipStream_t)stream;
     for (int d = 0; d < max_sparsity; ++d) {
         LevelArgs a;
@@ -1997,28 +1881,20 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         a.K = K; a.L = L; a.Lp = Lp; a.N = N; a.P = P; a.W = W;
         a.depth = d; a.Kmax = max_sparsity; a.connections = connections; a.NN = NN;
         a.NS = N + TRI(max_sparsity) + max_sparsity; a.stagger_ticks = stagger_ticks(); a.mode = mode;
-        a.gram = gram ? d_gram : nullptr; a.c0 = c0; a.ynorm2 = ynorm2;
-        a.gram16 = fp16_pass ? reinterpret_cast<const _Float16*>(d_gram + (size_t)K * CSC_TILE_COLS * GRAM_W) : nullptr;
-        a.c0h = fp16_pass ? c0h : nullptr;
+        a.gram16 = gram ? reinterpret_cast<const _Float16*>(d_gram) : nullptr;
+        a.xmax = gram ? d_gram + gram_halves(K) / 2 : nullptr;
+        a.c0h = c0h; a.ynorm2 = ynorm2;
         a.resid_in = (d == 0) ? d_signals : ws[d & 1];
         a.resid_out = (d + 1 < max_sparsity) ? ws[(d + 1) & 1] : nullptr;
         a.node_pos = d_node_pos; a.node_atom = d_node_atom; a.node_mse = d_node_mse; a.node_coef = d_node_coef;
         a.stats = d_stats; a.ts = ts;
         const size_t grid = (size_t)S * ts.F[d];
         if (grid > 0x7fffffffULL) FAIL(-11, "batch too large for one launch (%zu workgroups)", grid);
-        a.flags = nullptr; a.group = 1; a.S = S;
         const int span = timer_begin(st, d);
-        if (tiled) {
-            hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
-        } else if (gram && d >= 1 && d <= GRAM_MAX_DEPTH) {
-            // table kernel for the whole level, then the GEMM kernel for the nodes it flagged (usually none)
-            a.flags = flags;
-            hipLaunchKernelGGL(mmp_level_table_kernel, dim3((unsigned)grid), dim3(WG), lds_table, st, a);
-            a.group = group;
-            hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)((grid + group - 1) / group)), dim3(WG), lds, st, a);
-        } else {
-            hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
-        }
+        if (tiled) hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
+        else if (gram && d >= 1 && d <= GRAM_MAX_DEPTH)
+            hipLaunchKernelGGL(mmp_level_kernel<true>, dim3((unsigned)grid), dim3(WG), lds, st, a);
+        else hipLaunchKernelGGL(mmp_level_kernel<false>, dim3((unsigned)grid), dim3(WG), lds, st, a);
         timer_end(st, span);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) FAIL((int)e, "mmp_level_kernel launch failed at level %d: %s", d, hipGetErrorString(e));

@@ -58,8 +58,8 @@ def test_sizes_helpers():
     # per frontier node: N residual samples + the packed Cholesky factor (15 doubles at depth 5)
     # + max_sparsity coefficients; with the table: the signals' correlations (144 x 256 f32) and norms
     assert lib.csc_mmpdf_workspace_bytes(10, 738, 5, 3, 3, 0) == 2 * 10 * 3 * (738 + 15 + 5) * 8
-    assert lib.csc_mmpdf_workspace_bytes(10, 738, 5, 3, 3, 1) == 2 * 10 * 3 * (738 + 15 + 5) * 8 + 10 * (144 * 256 * 6 + 8) + 32
-    assert lib.csc_gram_elems(143, 492, 738) == 2 * 143 * 144 * 512 and lib.csc_gram_elems(145, 492, 738) == 0
+    assert lib.csc_mmpdf_workspace_bytes(10, 738, 5, 3, 3, 1) == 2 * 10 * 3 * (738 + 15 + 5) * 8 + 10 * (144 * 256 * 2 + 8)
+    assert lib.csc_gram_elems(143, 492, 738) == 143 * 144 * 512 + 16 and lib.csc_gram_elems(145, 492, 738) == 0
     assert lib.csc_gram_elems(143, 492, 492 + 256) == 0 and lib.csc_gram_elems(143, 492, 492 + 255) > 0
 
 

@@ -32,10 +32,11 @@ def test_gram_table(bank, golden_bank):
     K, L = b.shape
     P = 738 - L + 1
     raw = bank.gram_table(738).cpu().numpy()
-    g = raw[:K * 144 * 512].reshape(K, 144, 512)
-    h = raw[K * 144 * 512:].view(np.float16).reshape(2, K, 144, 512)
-    assert np.array_equal(h[0], g.astype(np.float16))                  # fp16 copy, and the same shifted by one
+    assert raw.size == K * 144 * 512 + 16
+    # two fp16 copies (the second shifted by one element), then max |entry| = max_k ||a_k||^2
+    h = raw[:K * 144 * 512].view(np.float16).reshape(2, K, 144, 512)
     assert np.array_equal(h[1][:, :, 1:], h[0][:, :, :-1]) and not h[1][:, :, 0].any()
+    g = h[0].astype(np.float64)
     perm = bank.bank32t.cpu().numpy()[16 * 9 * 512:].view(np.int32)[:144]
     assert not g[:, perm < 0].any() and not g[:, :, 2 * P - 1:].any()
     rng = np.random.default_rng(0)
@@ -43,8 +44,10 @@ def test_gram_table(bank, golden_bank):
         ks, c, dp = rng.integers(K), rng.integers(1, 144), rng.integers(-(P - 1), P)
         k = perm[c]
         lo, hi = max(0, -dp), min(L, L - dp)
-        want = float(np.dot(b[k, lo:hi], b[ks, lo + dp:hi + dp]))
-        assert abs(g[ks, c, dp + P - 1] - want) <= 1e-7 * max(1.0, abs(want)), (ks, c, dp)
+        want = np.float16(np.float32(np.dot(b[k, lo:hi], b[ks, lo + dp:hi + dp])))
+        assert abs(g[ks, c, dp + P - 1] - float(want)) <= 2.0 ** -11 * abs(float(want)) + 2.0 ** -24, (ks, c, dp)
+    xmax = float(raw[K * 144 * 512])
+    assert abs(xmax - float((b * b).sum(axis=1).max())) <= 1e-6
     assert bank.lib.csc_gram_elems(K, L, L + 256) == 0          # P = 257: no table, the GEMM path is used
 
 
