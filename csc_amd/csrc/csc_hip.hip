@@ -49,6 +49,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte access
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 8-byte access
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define R16_COPIES 8                   // fp16 residual window: copy c holds r[i + c], so every 8-element Hankel
+#define R16_CS 776                     // fragment is one aligned 16-byte LDS read; copy stride = 16 mod 128 bytes
 
 // Development aid (make prof): per-phase shader-clock totals of the level kernels, summed over workgroups
 // (slots 0-15: GEMM nodes, 16-31: table nodes; scripts/phase_prof.py names them).
@@ -89,7 +92,8 @@ struct LevelArgs {
     const _Float16* gram16;  // atom cross-correlation table in fp16, two copies ([2][K][144][GRAM_W]; copy 1 is
                           // shifted by one element so that every 4-element window starts dword-aligned), or
                           // nullptr (every level multiplies)
-    const float* xmax;    // max |table entry| = max_k ||a_k||^2 (scales the fp16 error bound)
+    const _Float16* bank16;  // the bank in fp16, blocked like bank32t with (k-group, column, 8 rows) fragments
+    const float* amax2;   // max_k ||a_k||^2 (scales the fp16 error bounds; also max |table entry|)
     _Float16* c0h;        // [S][144][256] f16: correlations of the ORIGINAL signals / ||y||, written by level 0
     double* ynorm2;       // [S] squared norm of the original signals, written by level 0
     TreeShape ts;
@@ -300,6 +304,72 @@ __device__ __forceinline__ void corr_rem_gemm(const float* __restrict__ tile, co
     }
 }
 
+// ---- the same product on the fp16 matrix cores (16x the fp32 rate): a FILTER, not the answer ---------------
+// acc = sum_l a16[k][l] * r16[p + l] with r16 = fl16(r / ||r||), v_mfma_f32_16x16x32_f16 (one per slab, row tile and
+// column tile), fp32 accumulation, same accumulator layout as corr_tile_gemm.  The caller widens its candidate
+// band by the fp16 rounding bound and re-scores in float64.
+// LDS: the residual window in R16_COPIES shifted fp16 copies (build_r16), the slab blocks double-buffered
+// (SLABF halves each) at slab16.
+__device__ __forceinline__ void build_r16(const double* r64, int N, float inv, _Float16* r16) {
+    for (int i = threadIdx.x; i < R16_COPIES * R16_CS; i += WG) {
+        const int c = i / R16_CS, e = i - c * R16_CS + c;
+        r16[i] = (_Float16)(e < N ? (float)r64[e] * inv : 0.f);
+    }
+}
+
+__device__ __forceinline__ void stage_blocks16(const _Float16* gslab, _Float16* lslab, int ni0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < (NT + 3) / 4; ++i) {
+        const int piece = ni0 + wave + 4 * i;                         // wave-uniform, one 1 KiB block each
+        if (piece < NT)
+            __builtin_amdgcn_global_load_lds((gptr_t)(gslab + piece * BLKF + lane * 8),
+                                             (lptr_t)(lslab + piece * BLKF), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void corr_tile_gemm16(const _Float16* __restrict__ tile, const uint32_t* masks, int nslab,
+                                                 const _Float16* r16, _Float16* slab, f32x4 (&acc)[MT][NT]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // fragment (mi, slab s) of this lane: elements 64 wave + 16 mi + lr + 8 lq + 32 s ... + 7 of the window
+    const _Float16* ra = r16 + (lr & 7) * R16_CS + 64 * wave + (lr & 8) + 8 * lq;
+
+    uint32_t m = __builtin_amdgcn_readfirstlane(masks[0]);
+    if (m) stage_blocks16(tile, slab, __builtin_ctz(m), wave, lane);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        uint32_t mn = 0;
+        if (s + 1 < nslab) {
+            mn = __builtin_amdgcn_readfirstlane(masks[s + 1]);
+            if (mn) stage_blocks16(tile + (size_t)(s + 1) * SLABF, slab + ((s + 1) & 1) * SLABF, __builtin_ctz(mn), wave, lane);
+        }
+        if (m) {
+            const int ni0 = __builtin_ctz(m);
+            const _Float16* sb = slab + (s & 1) * SLABF + lane * 8;
+            f16x8 af[MT], bf[2];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) af[mi] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 16 * mi);
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                if (ni >= ni0) {
+                    if (ni == ni0) bf[ni & 1] = *reinterpret_cast<const f16x8*>(sb + ni * BLKF);
+                    if (ni + 1 < NT) bf[(ni + 1) & 1] = *reinterpret_cast<const f16x8*>(sb + (ni + 1) * BLKF);
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni & 1], acc[mi][ni], 0, 0, 0);
+                }
+            }
+        }
+        m = mn;
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // bank packing: [K][L] f64 -> column tiles sorted by support, blocked [tile][slab][ni][32][16] f32
 // ------------------------------------------------------------------------------------------------
@@ -342,6 +412,33 @@ __global__ void bank_pack_kernel(const double* __restrict__ bank64, int K, int L
     const int k = meta[tile * META_INTS + 16 * ni + col16];
     const int l = slab * SLAB + row;
     out[i] = (k >= 0 && l < L) ? (float)bank64[(size_t)k * L + l] : 0.f;
+}
+
+// the same blocks in fp16 for v_mfma_f32_16x16x32_f16: [tile][slab][ni][k-group 4][column 16][8 rows], so that a
+// lane's B fragment (column lane & 15, rows 8 (lane >> 4) ... + 7) is 16 contiguous bytes and a wave reads a block
+// front to back
+__global__ void bank_pack16_kernel(const double* __restrict__ bank64, int K, int L, int nslab,
+                                   const int32_t* __restrict__ meta, _Float16* __restrict__ out, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i & 7), col16 = (int)((i >> 3) & 15), kg = (int)((i >> 7) & 3);
+    size_t t = i / BLKF;
+    const int ni = (int)(t % NT); t /= NT;
+    const int slab = (int)(t % nslab);
+    const int tile = (int)(t / nslab);
+    const int k = meta[tile * META_INTS + 16 * ni + col16];
+    const int l = slab * SLAB + 8 * kg + j;
+    out[i] = (k >= 0 && l < L) ? (_Float16)(float)bank64[(size_t)k * L + l] : (_Float16)0.f;
+}
+
+// amax2 = max_k ||a_k||^2 (one wave per atom)
+__global__ __launch_bounds__(64) void bank_norm_kernel(const double* __restrict__ bank64, int K, int L,
+                                                       float* __restrict__ amax2) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    double v = 0.0;
+    for (int l = lane; l < L; l += 64) { const double x = bank64[(size_t)k * L + l]; v = fma(x, x, v); }
+    v = wave_sum(v);
+    if (lane == 63) atomicMax(reinterpret_cast<unsigned*>(amax2), __float_as_uint((float)v * 1.0000002f));   // >= 0, rounded up
 }
 
 // masks[tile][slab]: bit ni set <=> the block holds a non-zero value
@@ -408,7 +505,7 @@ __global__ __launch_bounds__(WG) void sim_table_kernel(const double* __restrict_
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void gram_table_kernel(const double* __restrict__ bank64,
                                                         const int32_t* __restrict__ meta, int K, int L, int P,
-                                                        _Float16* __restrict__ gram16, float* __restrict__ xmax) {
+                                                        _Float16* __restrict__ gram16) {
     extern __shared__ double sm[];
     double* a_sel = sm;            // [L]
     double* a_k = sm + L;          // [L]
@@ -426,7 +523,6 @@ __global__ __launch_bounds__(WG) void gram_table_kernel(const double* __restrict
         a_k[i] = bank64[(size_t)k * L + i];
     }
     __syncthreads();
-    float big = 0.f;
     for (int dpi = tid; dpi < GRAM_W; dpi += WG) {
         double acc = 0.0;
         if (dpi < 2 * P - 1) {
@@ -437,10 +533,7 @@ __global__ __launch_bounds__(WG) void gram_table_kernel(const double* __restrict
         h0[dpi] = (_Float16)(float)acc;
         if (dpi + 1 < GRAM_W) h1[dpi + 1] = (_Float16)(float)acc;
         if (dpi == 0) h1[0] = (_Float16)0.f;
-        big = fmaxf(big, fabsf((float)acc));                          // NaN is skipped; Inf stays
     }
-    big = wave_max(big);
-    if ((tid & 63) == 63) atomicMax(reinterpret_cast<unsigned*>(xmax), __float_as_uint(big));   // big >= 0
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1070,10 +1163,11 @@ __device__ __forceinline__ void suppress_similar(const LevelArgs& a, NodeLds* sl
 
 // Selection of the node's children + their least squares, on the correlations held in acc
 // (reference src/csc/mmp.py:210-231 and :61-70).  `band` is the width below the maximum inside which an entry
-// may be the float64 maximum: every such entry is re-scored in float64.  ROWS: row layout, acc holds the fp16
-// table values (wide band); returns false if the node cannot be settled that way (the caller then multiplies
-// its residual after all and repeats the node from the start, with identical results).
-template <bool ROWS>
+// may be the float64 maximum: every such entry is re-scored in float64.  ROWS: row layout (table nodes).
+// EXACT = false: acc comes from an fp16 filter (wide band); returns false if the node cannot be settled that way
+// (more than CAND_CAP entries in the band, or the value 0 of suppressed entries inside it): the caller then
+// repeats the node from the start on more exact correlations, with identical results.
+template <bool ROWS, bool EXACT>
 __device__ __forceinline__ bool select_children(const LevelArgs& a, NodeLds* sl, const double* r64, uint32_t* simrow,
                                                 size_t s, int j, int nch, float band, f32x4 (&acc)[MT][NT]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1107,7 +1201,7 @@ __device__ __forceinline__ bool select_children(const LevelArgs& a, NodeLds* sl,
         const float m32 = fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
         const float tau = m32 - band;
         const bool zero_band = (0.f >= tau);
-        if (ROWS && zero_band) return false;       // the value 0 of suppressed entries may compete: exact path
+        if (!EXACT && zero_band) return false;     // the value 0 of suppressed entries may compete: exact path
         // (b) every unsuppressed entry inside the error band of the maximum is a candidate (NaN >= tau is
         //     false).  Only the few lanes whose own maximum reaches the band look at their 144 entries: a
         //     dense, branch-free bit mask first (straight-line code with a branch per entry made the
@@ -1139,7 +1233,7 @@ __device__ __forceinline__ bool select_children(const LevelArgs& a, NodeLds* sl,
                 }
             }
         }
-        if (!ROWS && zero_band) {                  // degenerate: the value 0 of the suppressed entries competes
+        if (EXACT && zero_band) {                  // degenerate: the value 0 of the suppressed entries competes
             int first_supp = 0x7fffffff;
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
@@ -1148,15 +1242,16 @@ __device__ __forceinline__ bool select_children(const LevelArgs& a, NodeLds* sl,
 #pragma unroll
                     for (int ni = 0; ni < NT; ++ni)
                         if (is_supp(acc[mi][ni][rg]))
-                            first_supp = min(first_supp, entry_pos<false>(mi, rg) * Kb + permv[ni]);
+                            first_supp = min(first_supp, entry_pos<ROWS>(mi, rg) * Kb +
+                                                         (ROWS ? sl->perm[entry_col<true>(mi, ni)] : permv[ni]));
             first_supp = wave_min(first_supp);
             if (lane == 0) sl->wsupp[wave] = first_supp;
         }
         __syncthreads();
         PROF_MARK(3);
         const int ncand_raw = sl->cand_cnt;
-        if (ROWS && ncand_raw > CAND_CAP) return false;
-        if (!ROWS && ncand_raw > CAND_CAP) {
+        if (!EXACT && ncand_raw > CAND_CAP) return false;
+        if (EXACT && ncand_raw > CAND_CAP) {
             // overflow (never seen on real data): fall back to the fp32 arg-max, lowest index
             int bi = 0x7fffffff;
 #pragma unroll
@@ -1167,7 +1262,8 @@ __device__ __forceinline__ bool select_children(const LevelArgs& a, NodeLds* sl,
                     for (int ni = 0; ni < NT; ++ni) {
                         const float x = acc[mi][ni][rg];
                         const float e = is_supp(x) ? 0.f : x;
-                        if (e == m32) bi = min(bi, entry_pos<false>(mi, rg) * Kb + permv[ni]);
+                        if (e == m32) bi = min(bi, entry_pos<ROWS>(mi, rg) * Kb +
+                                                   (ROWS ? sl->perm[entry_col<true>(mi, ni)] : permv[ni]));
                     }
             bi = wave_min(bi);
             if (lane == 0) sl->widx[wave] = bi;
@@ -1189,6 +1285,34 @@ __device__ __forceinline__ int children_of(const LevelArgs& a, int j) {
         if ((long long)j + (long long)r * stride < Fc) ++nch; else break;
     }
     return nch;
+}
+
+// Level 0 keeps the signal's correlations, divided by ||y||, in fp16 for the table nodes of the levels below.
+// Each wave turns its (64 positions x 16 columns) pieces through LDS (tp: 4 x 16 x 72 halves, free after the
+// GEMM) so that a store instruction writes eight whole 128-byte lines; straight from the MFMA layout it would
+// write 16 x 32-byte fragments.
+__device__ __forceinline__ void store_c0h(const LevelArgs& a, size_t s, float scale, _Float16* tp0,
+                                          const f32x4 (&acc)[MT][NT]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    __syncthreads();                                                 // every wave is done with the slab buffers
+    _Float16* tp = tp0 + wave * (16 * 72);                           // [16 columns][64 + 8]
+    _Float16* dst = a.c0h + (size_t)s * CSC_TILE_COLS * CSC_TILE_ROWS + 64 * wave + 8 * (lane & 7);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+            *reinterpret_cast<f16x4*>(tp + lr * 72 + 16 * mi + 4 * lq) =
+                __builtin_convertvector(acc[mi][ni] * scale, f16x4);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int col = (lane >> 3) + 8 * h;
+            const uint4 v = *reinterpret_cast<const uint4*>(tp + col * 72 + 8 * (lane & 7));
+            *reinterpret_cast<uint4*>(dst + (size_t)(16 * ni + col) * CSC_TILE_ROWS) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // ---- the level kernel ---------------------------------------------------------------------------------------
@@ -1234,54 +1358,64 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2);
     PROF_MARK(0);
     f32x4 acc[MT][NT];
+    // fp16 rounding bounds, relative to ||a|| ||r|| with the norms taken as 1 (see the callers' scaling):
+    //   E_MFMA16: both operands rounded (2 x 2^-11), fp32 accumulation over L terms (2^-14), cross terms
+    //   E_SUB:    absolute 2^-25 per operand that is subnormal in fp16, summed over a window (sqrt(L) each side)
+    const float am2 = *a.amax2, am = sqrtf(am2);
+    const float E_MFMA16 = 9.765625e-04f + DELTA_REL + 1e-6f;
+    const float E_SUB = 2.9802322e-08f * sqrtf((float)L) * (1.f + am);
+    const bool amax_ok = am2 > 1e-6f && am2 < 1e4f;
     if (TABLES) {
         const double y2 = a.ynorm2[s];
-        const float xm = *a.xmax;
-        if (y2 > 1e-30 && y2 < 1e30 && rnorm2 * 4096.0 >= y2 && xm > 1e-6f && xm < 1e4f) {
+        if (amax_ok && y2 > 1e-30 && y2 < 1e30 && rnorm2 * 4096.0 >= y2) {
             float csum = 0.f;
             for (int i = 0; i < d; ++i) csum += fabsf((float)sl->coefpar[i]);
             const float ynorm = (float)sqrt(y2);
-            // Error of an entry of acc, in units of ||y||: every fp16 operand is rounded by at most 2^-11
-            // relative (2^-25 absolute when subnormal), |C_y| <= ||y|| sqrt(xm), |X| <= xm; the level-0 GEMM and
-            // the fp32 arithmetic here add 2^-14 and (d + 1) 2^-23 of the same magnitudes.  An entry that can
-            // be the float64 maximum lies within twice that of the computed maximum.
-            const float mag = sqrtf(xm) + xm * csum / ynorm;
-            const float eps = (4.8828125e-04f + DELTA_REL + 1e-6f) * mag + 5.9604645e-08f * (1.f + csum / ynorm);
+            // Error of an entry of acc, in units of ||y||: C_y / ||y|| carries the level-0 fp16 MFMA bound plus
+            // its own rounding to fp16 (2^-11), |C_y| <= ||y|| am; every table entry is rounded by 2^-11
+            // (2^-25 absolute when subnormal), |X| <= am2; the fp32 arithmetic here adds (d + 1) 2^-23.
+            // An entry that can be the float64 maximum lies within twice that of the computed maximum.
+            const float cr = csum / ynorm;
+            const float eps = (E_MFMA16 + 4.8828125e-04f) * am + E_SUB + (4.8828125e-04f + 1e-6f) * am2 * cr +
+                              2.9802322e-08f * (1.f + cr);
             fill_from_tables16(a, sl, s, d, a.P, ynorm, acc);
             PROF_MARK(1);
-            if (select_children<true>(a, sl, r64, simrow, s, j, nch, 2.f * eps, acc)) {
+            if (select_children<true, false>(a, sl, r64, simrow, s, j, nch, 2.f * eps, acc)) {
                 PROF_MARK(9);
                 return;
             }
             if (tid == 0 && a.stats) atomicAdd(&a.stats[3], 1);
         }
-        PROF_INIT(0);                                                // what follows counts as the GEMM kernel's
+        PROF_INIT(0);                                                // what follows counts as a GEMM node
     }
-    // ---- correlations on the matrix cores ----------------------------------------------------------
-    corr_tile_gemm(a.bank32t, sl->masks, (L + SLAB - 1) / SLAB, r32 + 64 * wave + lr + lq, slab, acc);
-    if (!TABLES && d == 0 && a.c0h) {
-        // keep the signal's correlations, divided by ||y||, in fp16 for the levels below.  Each wave turns
-        // its (64 positions x 16 columns) pieces through LDS so that a store instruction writes eight whole
-        // 128-byte lines (straight from the MFMA layout it would write 16 x 32-byte fragments).
-        __syncthreads();                                             // every wave is done with the slab buffers
-        _Float16* tp = reinterpret_cast<_Float16*>(slab) + wave * (16 * 72);          // [16 columns][64 + 8]
-        const float inv = rnorm2 > 0.0 ? (float)(1.0 / sqrt(rnorm2)) : 0.f;
-        _Float16* dst = a.c0h + (size_t)s * CSC_TILE_COLS * CSC_TILE_ROWS + 64 * wave + 8 * (lane & 7);
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) {
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-                *reinterpret_cast<f16x4*>(tp + lr * 72 + 16 * mi + 4 * lq) =
-                    __builtin_convertvector(acc[mi][ni] * inv, f16x4);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int col = (lane >> 3) + 8 * h;
-                const uint4 v = *reinterpret_cast<const uint4*>(tp + col * 72 + 8 * (lane & 7));
-                *reinterpret_cast<uint4*>(dst + (size_t)(16 * ni + col) * CSC_TILE_ROWS) = v;
-            }
-            __builtin_amdgcn_wave_barrier();
+    // ---- correlations on the fp16 matrix cores, in units of ||r||, as a filter ------------------------------
+    const bool filter16 = a.bank16 && amax_ok && rnorm2 > 1e-30 && rnorm2 < 1e30;
+    bool stored = false;
+    if (filter16) {
+        _Float16* slab16 = reinterpret_cast<_Float16*>(slab);                 // [2][SLABF] halves
+        _Float16* r16 = slab16 + 2 * SLABF;                                   // [R16_COPIES][R16_CS]
+        __syncthreads();                                                      // simrow (same LDS) no longer read
+        build_r16(r64, N, (float)(1.0 / sqrt(rnorm2)), r16);
+        __syncthreads();
+        corr_tile_gemm16(a.bank16, sl->masks, (L + SLAB - 1) / SLAB, r16, slab16, acc);
+        if (!TABLES && d == 0 && a.c0h) {
+            store_c0h(a, s, 1.f, reinterpret_cast<_Float16*>(slab), acc);
+            if (tid == 0) a.ynorm2[s] = rnorm2;
+            stored = true;
         }
+        PROF_MARK(1);
+        if (select_children<false, false>(a, sl, r64, simrow, s, j, nch, 2.f * (E_MFMA16 * am + E_SUB), acc)) {
+            __syncthreads();
+            PROF_MARK(9);
+            return;
+        }
+        if (tid == 0 && a.stats) atomicAdd(&a.stats[3], 1);
+        __syncthreads();
+    }
+    // ---- correlations on the fp32 matrix cores ------------------------------------------------------
+    corr_tile_gemm(a.bank32t, sl->masks, (L + SLAB - 1) / SLAB, r32 + 64 * wave + lr + lq, slab, acc);
+    if (!TABLES && d == 0 && a.c0h && !stored) {
+        store_c0h(a, s, rnorm2 > 0.0 ? (float)(1.0 / sqrt(rnorm2)) : 0.f, reinterpret_cast<_Float16*>(slab), acc);
         if (tid == 0) a.ynorm2[s] = rnorm2;
     }
     PROF_MARK(1);
@@ -1298,7 +1432,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
         return;
     }
 #endif
-    select_children<false>(a, sl, r64, simrow, s, j, nch, delta, acc);
+    select_children<false, true>(a, sl, r64, simrow, s, j, nch, delta, acc);
     __syncthreads();
     PROF_MARK(9);
 }
@@ -1648,6 +1782,14 @@ static int ceil8(int v) { return (v + 7) & ~7; }
 static int n_tiles(int K) { return (K + CSC_TILE_COLS - 1) / CSC_TILE_COLS; }
 static int n_slabs(int L) { return (L + SLAB - 1) / SLAB; }
 static size_t tile_floats(int K, int L) { return (size_t)n_tiles(K) * n_slabs(L) * SLABF; }
+// packed bank buffer: [fp32 tiles][meta per tile][fp16 tiles][amax2 + spare (16 floats)]
+static size_t bank16_offset(int K, int L) { return tile_floats(K, L) + (size_t)n_tiles(K) * META_INTS; }
+static const _Float16* bank_tiles16(const float* d_bank32t, int K, int L) {
+    return reinterpret_cast<const _Float16*>(d_bank32t + bank16_offset(K, L));
+}
+static const float* bank_amax2(const float* d_bank32t, int K, int L) {
+    return d_bank32t + bank16_offset(K, L) + tile_floats(K, L) / 2;
+}
 static const int32_t* bank_meta(const float* d_bank32t, int K, int L) {
     return reinterpret_cast<const int32_t*>(d_bank32t + tile_floats(K, L));
 }
@@ -1721,7 +1863,7 @@ const char* csc_last_error(void) { return g_err; }
 
 size_t csc_bank32_elems(int K, int L) {
     if (K <= 0 || L <= 0) return 0;
-    return tile_floats(K, L) + (size_t)n_tiles(K) * META_INTS;
+    return bank16_offset(K, L) + tile_floats(K, L) / 2 + 16;
 }
 
 int csc_sim_words(int N, int L) {
@@ -1744,6 +1886,11 @@ int csc_bank_pack(const double* d_bank64, int K, int L, float* d_bank32t, void* 
     hipLaunchKernelGGL(bank_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_bank64, K, L,
                        nslab, meta, d_bank32t, total);
     hipLaunchKernelGGL(bank_mask_kernel, dim3(nslab, ntile), dim3(256), 0, st, d_bank32t, nslab, meta);
+    hipLaunchKernelGGL(bank_pack16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_bank64, K, L,
+                       nslab, meta, const_cast<_Float16*>(bank_tiles16(d_bank32t, K, L)), total);
+    float* amax2 = const_cast<float*>(bank_amax2(d_bank32t, K, L));
+    if (hipMemsetAsync(amax2, 0, 16 * sizeof(float), st) != hipSuccess) FAIL(-1, "csc_bank_pack: hipMemsetAsync failed");
+    hipLaunchKernelGGL(bank_norm_kernel, dim3(K), dim3(64), 0, st, d_bank64, K, L, amax2);
     return launch_status("bank_pack kernels");
 }
 
@@ -1807,7 +1954,7 @@ static size_t gram_halves(int K) { return 2 * (size_t)K * CSC_TILE_COLS * GRAM_W
 size_t csc_gram_elems(int K, int L, int N) {
     const int P = N - L + 1;
     if (K <= 0 || K > CSC_TILE_COLS || P <= 0 || P > CSC_TILE_ROWS) return 0;
-    return gram_halves(K) / 2 + 16;                                  // in floats: the copies + max |entry| (+ spare)
+    return gram_halves(K) / 2;                                       // in floats
 }
 
 int csc_gram_table(const double* d_bank64, const float* d_bank32t, int K, int L, int N, float* d_gram,
@@ -1818,12 +1965,9 @@ int csc_gram_table(const double* d_bank64, const float* d_bank32t, int K, int L,
         FAIL(-9, "csc_gram_table: needs K <= %d and 1 <= P <= %d (got K = %d, P = %d)", CSC_TILE_COLS,
              CSC_TILE_ROWS, K, P);
     clear_stale_error();
-    float* xmax = d_gram + gram_halves(K) / 2;
-    if (hipMemsetAsync(xmax, 0, 16 * sizeof(float), (hipStream_t)stream) != hipSuccess)
-        FAIL(-1, "csc_gram_table: hipMemsetAsync failed");
     hipLaunchKernelGGL(gram_table_kernel, dim3(CSC_TILE_COLS, K), dim3(WG), (size_t)2 * L * sizeof(double),
                        (hipStream_t)stream, d_bank64, bank_meta(d_bank32t, K, L), K, L, P,
-                       reinterpret_cast<_Float16*>(d_gram), xmax);
+                       reinterpret_cast<_Float16*>(d_gram));
     return launch_status("gram_table_kernel");
 }
 
@@ -1882,7 +2026,8 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         a.depth = d; a.Kmax = max_sparsity; a.connections = connections; a.NN = NN;
         a.NS = N + TRI(max_sparsity) + max_sparsity; a.stagger_ticks = stagger_ticks(); a.mode = mode;
         a.gram16 = gram ? reinterpret_cast<const _Float16*>(d_gram) : nullptr;
-        a.xmax = gram ? d_gram + gram_halves(K) / 2 : nullptr;
+        a.bank16 = (!tiled && !getenv("CSC_NO_FP16_MFMA")) ? bank_tiles16(d_bank32t, K, L) : nullptr;
+        a.amax2 = bank_amax2(d_bank32t, K, L);
         a.c0h = c0h; a.ynorm2 = ynorm2;
         a.resid_in = (d == 0) ? d_signals : ws[d & 1];
         a.resid_out = (d + 1 < max_sparsity) ? ws[(d + 1) & 1] : nullptr;

@@ -51,15 +51,15 @@ def test_sizes_helpers():
     from csc_amd import _lib
     lib = _lib.lib()
     # per 144-atom tile: 16 slabs x 9 column blocks x (32 x 16) floats + 208 ints of metadata
-    assert lib.csc_bank32_elems(143, 492) == 512 * 144 + 208
-    assert lib.csc_bank32_elems(145, 492) == 2 * (512 * 144 + 208)
+    assert lib.csc_bank32_elems(143, 492) == 512 * 144 + 208 + 256 * 144 + 16
+    assert lib.csc_bank32_elems(145, 492) == 2 * (512 * 144 + 208 + 256 * 144) + 16
     assert lib.csc_sim_words(738, 492) == 2 * ((2 * 247 - 1 + 63) // 64)
     assert lib.csc_sim_words(100, 492) == 0
     # per frontier node: N residual samples + the packed Cholesky factor (15 doubles at depth 5)
     # + max_sparsity coefficients; with the table: the signals' correlations (144 x 256 f32) and norms
     assert lib.csc_mmpdf_workspace_bytes(10, 738, 5, 3, 3, 0) == 2 * 10 * 3 * (738 + 15 + 5) * 8
     assert lib.csc_mmpdf_workspace_bytes(10, 738, 5, 3, 3, 1) == 2 * 10 * 3 * (738 + 15 + 5) * 8 + 10 * (144 * 256 * 2 + 8)
-    assert lib.csc_gram_elems(143, 492, 738) == 143 * 144 * 512 + 16 and lib.csc_gram_elems(145, 492, 738) == 0
+    assert lib.csc_gram_elems(143, 492, 738) == 143 * 144 * 512 and lib.csc_gram_elems(145, 492, 738) == 0
     assert lib.csc_gram_elems(143, 492, 492 + 256) == 0 and lib.csc_gram_elems(143, 492, 492 + 255) > 0
 
 

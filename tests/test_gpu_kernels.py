@@ -32,8 +32,8 @@ def test_gram_table(bank, golden_bank):
     K, L = b.shape
     P = 738 - L + 1
     raw = bank.gram_table(738).cpu().numpy()
-    assert raw.size == K * 144 * 512 + 16
-    # two fp16 copies (the second shifted by one element), then max |entry| = max_k ||a_k||^2
+    assert raw.size == K * 144 * 512
+    # two fp16 copies, the second shifted by one element
     h = raw[:K * 144 * 512].view(np.float16).reshape(2, K, 144, 512)
     assert np.array_equal(h[1][:, :, 1:], h[0][:, :, :-1]) and not h[1][:, :, 0].any()
     g = h[0].astype(np.float64)
@@ -46,8 +46,6 @@ def test_gram_table(bank, golden_bank):
         lo, hi = max(0, -dp), min(L, L - dp)
         want = np.float16(np.float32(np.dot(b[k, lo:hi], b[ks, lo + dp:hi + dp])))
         assert abs(g[ks, c, dp + P - 1] - float(want)) <= 2.0 ** -11 * abs(float(want)) + 2.0 ** -24, (ks, c, dp)
-    xmax = float(raw[K * 144 * 512])
-    assert abs(xmax - float((b * b).sum(axis=1).max())) <= 1e-6
     assert bank.lib.csc_gram_elems(K, L, L + 256) == 0          # P = 257: no table, the GEMM path is used
 
 
@@ -73,6 +71,15 @@ def test_bank_pack(bank, golden_bank):
     # the zero padding that is skipped: ~30 % of the (slab, column tile) blocks
     active = sum(9 - (int(m) & -int(m)).bit_length() + 1 for m in masks if m)
     assert active < 0.75 * nslab * 9
+    # the same blocks in fp16, [slab][column tile][k-group 4][column 16][8 rows], then max_k ||a_k||^2
+    off = nslab * 9 * 512 + 208
+    t16 = raw[off:off + nslab * 9 * 256].view(np.float16).reshape(nslab, 9, 4, 16, 8)
+    img16 = t16.transpose(0, 2, 4, 1, 3).reshape(nslab * 32, 144)      # [row][column]
+    err = np.abs(img16.astype(np.float64) - img)                        # round to nearest: 2^-11 relative, subnormals kept
+    assert (err <= 2.0 ** -11 * np.abs(img) + 2.0 ** -25).all() and (img16 != 0).sum() > 0.99 * (img != 0).sum()
+    amax2 = float(raw[off + nslab * 9 * 256])
+    want = float((b * b).sum(axis=1).max())
+    assert want <= amax2 <= want * (1 + 1e-6)
 
 
 def test_correlate_matches_reference(bank, golden_signals):
