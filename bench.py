@@ -242,7 +242,10 @@ def main():
                 "value": S * msteps / mfma_elapsed, "unit": "signals/s",
                 "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                             "launch_ms_avg": launch_ms_m, "flops_per_launch": flops_per_launch,
+                             "launch_ms_avg": launch_ms_m,
+                             "launch_ms_by_level": {str(d): float(np.mean([ms for lv, ms in spans_m if lv == d]))
+                                                    for d in range(MAX_SPARSITY)},
+                             "flops_per_launch": flops_per_launch,
                              "flops_per_signal": flops_per_signal,
                              "mfma_issued": {"tflops": issued, "frac_of_peak": issued / FP32_MFMA_PEAK_TFLOPS,
                                              "blocks_per_node": blocks, "of_dense_blocks": nslab * 9,

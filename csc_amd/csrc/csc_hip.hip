@@ -43,7 +43,7 @@
 #define TRI(n) ((n) * ((n) + 1) / 2)
 #define DELTA_REL 6.103515625e-05f      // 2^-14: fp32 candidate band, in units of ||residual||
 #define GRAM_W (2 * CSC_TILE_ROWS)     // shifts per (atom, column) row of the cross-correlation table
-#define GRAM_MAX_DEPTH 6               // a node at depth d streams (1 + d) x 147 KB; past ~7 slices the GEMM is cheaper
+#define GRAM_MAX_DEPTH 2               // deeper nodes: the fp16 matrix-core filter is cheaper than (1 + d) table slices
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte access
@@ -310,25 +310,67 @@ __device__ __forceinline__ void corr_rem_gemm(const float* __restrict__ tile, co
 // band by the fp16 rounding bound and re-scores in float64.
 // LDS: the residual window in R16_COPIES shifted fp16 copies (build_r16), the slab blocks double-buffered
 // (SLABF halves each) at slab16.
-__device__ __forceinline__ void build_r16(const double* r64, int N, float inv, _Float16* r16) {
+// `first` holds elements tid + 256 u (u < 4) of the window, zero beyond N, still in registers from the prologue
+// (whole window when N <= 1024); longer signals re-read the LDS copy.
+template <bool REGS>
+__device__ __forceinline__ void build_r16(const double* r64, int N, float inv, const double (&first)[4], _Float16* r16) {
+    if (REGS && N <= 4 * WG) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = threadIdx.x + WG * u;
+            const _Float16 h = (_Float16)((float)first[u] * inv);
+#pragma unroll
+            for (int c = 0; c < R16_COPIES; ++c)
+                if (e >= c && e - c < R16_CS) r16[c * R16_CS + e - c] = h;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < R16_COPIES * R16_CS; i += WG) {
         const int c = i / R16_CS, e = i - c * R16_CS + c;
         r16[i] = (_Float16)(e < N ? (float)r64[e] * inv : 0.f);
     }
 }
 
-__device__ __forceinline__ void stage_blocks16(const _Float16* gslab, _Float16* lslab, int ni0, int wave, int lane) {
+// Staging: a ring of RING16 slabs (9 KiB each).  The nine blocks of a slab are copied global -> LDS by
+// global_load_lds_dwordx4, one block per wave instruction: wave w copies blocks w, w + 4 (and 8 for w = 0), the
+// same number for every slab, so "slab s has landed" is an s_waitcnt vmcnt with a constant: the copies of the
+// two slabs issued after it may still be in flight.  Issued three slabs ahead, a copy has ~3 slabs of MFMAs to
+// cross the L2 latency (one slab ahead, the loop ran at that latency, not at the MFMA rate).
+#define RING16 4
+__device__ __forceinline__ void stage_slab16(const _Float16* gslab, _Float16* lslab, int wave, int lane) {
+    __builtin_amdgcn_global_load_lds((gptr_t)(gslab + wave * BLKF + lane * 8), (lptr_t)(lslab + wave * BLKF), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(gslab + (wave + 4) * BLKF + lane * 8),
+                                     (lptr_t)(lslab + (wave + 4) * BLKF), 16, 0, 0);
+    if (wave == 0)
+        __builtin_amdgcn_global_load_lds((gptr_t)(gslab + 8 * BLKF + lane * 8), (lptr_t)(lslab + 8 * BLKF), 16, 0, 0);
+}
+// s_waitcnt vmcnt(n) only (expcnt, lgkmcnt left at their maxima): simm16 = vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8
+// | vmcnt[5:4] << 14
+#define WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))
+
+template <int NI0>
+__device__ __forceinline__ void slab_mfma16(const _Float16* rs, const _Float16* sb, f32x4 (&acc)[MT][NT]) {
+    constexpr int AHEAD = 3;                                          // B fragments in flight ahead of the MFMAs
+    f16x8 af[MT], bf[AHEAD + 1];
 #pragma unroll
-    for (int i = 0; i < (NT + 3) / 4; ++i) {
-        const int piece = ni0 + wave + 4 * i;                         // wave-uniform, one 1 KiB block each
-        if (piece < NT)
-            __builtin_amdgcn_global_load_lds((gptr_t)(gslab + piece * BLKF + lane * 8),
-                                             (lptr_t)(lslab + piece * BLKF), 16, 0, 0);
+    for (int mi = 0; mi < MT; ++mi) af[mi] = *reinterpret_cast<const f16x8*>(rs + 16 * mi);
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q)
+        if (NI0 + q < NT) bf[q] = *reinterpret_cast<const f16x8*>(sb + (NI0 + q) * BLKF);
+#pragma unroll
+    for (int ni = NI0; ni < NT; ++ni) {
+        if (ni + AHEAD < NT)
+            bf[(ni - NI0 + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const f16x8*>(sb + (ni + AHEAD) * BLKF);
+        __builtin_amdgcn_sched_barrier(0);                            // keep the reads where they are written
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[(ni - NI0) % (AHEAD + 1)], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 __device__ __forceinline__ void corr_tile_gemm16(const _Float16* __restrict__ tile, const uint32_t* masks, int nslab,
-                                                 const _Float16* r16, _Float16* slab, f32x4 (&acc)[MT][NT]) {
+                                                 const _Float16* r16, _Float16* ring, f32x4 (&acc)[MT][NT]) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
@@ -339,35 +381,30 @@ __device__ __forceinline__ void corr_tile_gemm16(const _Float16* __restrict__ ti
     // fragment (mi, slab s) of this lane: elements 64 wave + 16 mi + lr + 8 lq + 32 s ... + 7 of the window
     const _Float16* ra = r16 + (lr & 7) * R16_CS + 64 * wave + (lr & 8) + 8 * lq;
 
-    uint32_t m = __builtin_amdgcn_readfirstlane(masks[0]);
-    if (m) stage_blocks16(tile, slab, __builtin_ctz(m), wave, lane);
-    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RING16 - 1; ++q)
+        if (q < nslab) stage_slab16(tile + (size_t)q * SLABF, ring + q * SLABF, wave, lane);
     for (int s = 0; s < nslab; ++s) {
-        uint32_t mn = 0;
-        if (s + 1 < nslab) {
-            mn = __builtin_amdgcn_readfirstlane(masks[s + 1]);
-            if (mn) stage_blocks16(tile + (size_t)(s + 1) * SLABF, slab + ((s + 1) & 1) * SLABF, __builtin_ctz(mn), wave, lane);
-        }
+        // slab s has landed (this wave's copies), then everybody's: the barrier also says that every wave is done
+        // reading slab s - 1, whose ring slot the copy issued below overwrites
+        const int later = min(RING16 - 2, nslab - 1 - s);            // slabs issued after s and still allowed in flight
+        if (wave == 0) { if (later == 2) WAIT_VM(6); else if (later == 1) WAIT_VM(3); else WAIT_VM(0); }
+        else           { if (later == 2) WAIT_VM(4); else if (later == 1) WAIT_VM(2); else WAIT_VM(0); }
+        __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));   // lgkmcnt(0): own LDS reads done
+        __builtin_amdgcn_s_barrier();
+        if (s + RING16 - 1 < nslab)
+            stage_slab16(tile + (size_t)(s + RING16 - 1) * SLABF, ring + ((s + RING16 - 1) % RING16) * SLABF, wave, lane);
+        const uint32_t m = __builtin_amdgcn_readfirstlane(masks[s]);
         if (m) {
+            // column tiles below ctz(m) hold only zero padding in this slab; skipped in steps of three tiles so
+            // that each variant is straight-line code (all fragment reads in flight before the first MFMA)
             const int ni0 = __builtin_ctz(m);
-            const _Float16* sb = slab + (s & 1) * SLABF + lane * 8;
-            f16x8 af[MT], bf[2];
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) af[mi] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 16 * mi);
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
-                if (ni >= ni0) {
-                    if (ni == ni0) bf[ni & 1] = *reinterpret_cast<const f16x8*>(sb + ni * BLKF);
-                    if (ni + 1 < NT) bf[(ni + 1) & 1] = *reinterpret_cast<const f16x8*>(sb + (ni + 1) * BLKF);
-#pragma unroll
-                    for (int mi = 0; mi < MT; ++mi)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni & 1], acc[mi][ni], 0, 0, 0);
-                }
-            }
+            const _Float16* sb = ring + (s % RING16) * SLABF + lane * 8;
+            const _Float16* rs = ra + 32 * s;
+            (void)ni0; slab_mfma16<0>(rs, sb, acc);
         }
-        m = mn;
-        __syncthreads();
     }
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -754,7 +791,7 @@ __device__ __forceinline__ void node_of_block(int Fd, size_t& s, int& j) {
 // factor.  Returns the fp32 candidate band delta = 2^-14 * ||residual||.  Ends with a barrier.
 __device__ __forceinline__ float node_prologue(const LevelArgs& a, NodeLds* sl, double* r64, float* r32,
                                                int Npad, int R32, const double* __restrict__ rin, size_t s, int j,
-                                               double& rnorm2_out) {
+                                               double& rnorm2_out, double (&first)[4]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, d = a.depth;
     double ss = 0.0;
@@ -771,6 +808,7 @@ __device__ __forceinline__ float node_prologue(const LevelArgs& a, NodeLds* sl, 
             if (i < Npad) r64[i] = v[u];
             if (i < R32) r32[i] = (float)v[u];
             ss = fma(v[u], v[u], ss);
+            if (i0 == 0) first[u] = v[u];                             // elements tid + 256 u, kept for build_r16
         }
     }
     if (tid < d) {
@@ -1201,7 +1239,8 @@ __device__ __forceinline__ bool select_children(const LevelArgs& a, NodeLds* sl,
         const float m32 = fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
         const float tau = m32 - band;
         const bool zero_band = (0.f >= tau);
-        if (!EXACT && zero_band) return false;     // the value 0 of suppressed entries may compete: exact path
+        // the value 0 of suppressed entries may compete: exact path (nothing is suppressed for the first child)
+        if (!EXACT && zero_band && t > 0) return false;
         // (b) every unsuppressed entry inside the error band of the maximum is a candidate (NaN >= tau is
         //     false).  Only the few lanes whose own maximum reaches the band look at their 144 entries: a
         //     dense, branch-free bit mask first (straight-line code with a branch per entry made the
@@ -1268,7 +1307,7 @@ __device__ __forceinline__ bool select_children(const LevelArgs& a, NodeLds* sl,
             bi = wave_min(bi);
             if (lane == 0) sl->widx[wave] = bi;
         }
-        rescore_and_choose(a, sl, r64, ncand_raw, zero_band);
+        rescore_and_choose(a, sl, r64, ncand_raw, EXACT && zero_band);   // the filter gets here only with nothing suppressed
         PROF_MARK(5);
         const int jc = j + t * stride;                               // child's index in level d+1
         const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
@@ -1342,7 +1381,8 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     uint32_t* simrow = reinterpret_cast<uint32_t*>(slab);             // aliases the slabs
     double* r64 = lds_raw + SLABF;                                    // [Npad]   (2*SLABF floats = SLABF doubles)
     float* r32 = reinterpret_cast<float*>(r64 + Npad);                // [R32]
-    NodeLds* sl = reinterpret_cast<NodeLds*>(r32 + ((R32 + 3) & ~3));
+    _Float16* r16 = reinterpret_cast<_Float16*>(r32 + ((R32 + 3) & ~3));           // [R16_COPIES][R16_CS]
+    NodeLds* sl = reinterpret_cast<NodeLds*>(r16 + R16_COPIES * R16_CS);
 
     const int Fd = a.ts.F[d];
     size_t s;
@@ -1354,8 +1394,8 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
 
     PROF_INIT(TABLES ? 16 : 0);
     const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
-    double rnorm2;
-    const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2);
+    double rnorm2, first[4];
+    const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2, first);
     PROF_MARK(0);
     f32x4 acc[MT][NT];
     // fp16 rounding bounds, relative to ||a|| ||r|| with the norms taken as 1 (see the callers' scaling):
@@ -1392,12 +1432,10 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     const bool filter16 = a.bank16 && amax_ok && rnorm2 > 1e-30 && rnorm2 < 1e30;
     bool stored = false;
     if (filter16) {
-        _Float16* slab16 = reinterpret_cast<_Float16*>(slab);                 // [2][SLABF] halves
-        _Float16* r16 = slab16 + 2 * SLABF;                                   // [R16_COPIES][R16_CS]
-        __syncthreads();                                                      // simrow (same LDS) no longer read
-        build_r16(r64, N, (float)(1.0 / sqrt(rnorm2)), r16);
-        __syncthreads();
-        corr_tile_gemm16(a.bank16, sl->masks, (L + SLAB - 1) / SLAB, r16, slab16, acc);
+        _Float16* ring = reinterpret_cast<_Float16*>(slab);                   // [RING16][SLABF] halves = the slab area
+        build_r16<!TABLES>(r64, N, (float)(1.0 / sqrt(rnorm2)), first, r16);   // table nodes rarely get here
+        __syncthreads();                                                      // r16 built; simrow (ring's LDS) no longer read
+        corr_tile_gemm16(a.bank16, sl->masks, (L + SLAB - 1) / SLAB, r16, ring, acc);
         if (!TABLES && d == 0 && a.c0h) {
             store_c0h(a, s, 1.f, reinterpret_cast<_Float16*>(slab), acc);
             if (tid == 0) a.ynorm2[s] = rnorm2;
@@ -1570,8 +1608,8 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled_kernel(const LevelArgs 
         if ((long long)j + (long long)r * stride < Fc) ++nch; else break;
     }
     const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
-    double rnorm2;
-    const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2);
+    double rnorm2, first[4];
+    const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2, first);
 
     f32x4 acc[MT][NT];
     int permv[NT];
@@ -1817,7 +1855,7 @@ static int make_shape(int Kmax, int c, int B, TreeShape* ts) {
 static size_t level_lds_bytes(int N, int Lp) {
     const int Npad = ceil4(N);
     const int R32 = CSC_TILE_ROWS + Lp + 4;
-    return (size_t)Npad * 8 + sizeof(NodeLds) + (size_t)ceil4(R32) * 4 + 2 * SLABF * 4;
+    return (size_t)Npad * 8 + sizeof(NodeLds) + (size_t)ceil4(R32) * 4 + 2 * SLABF * 4 + R16_COPIES * R16_CS * 2;
 }
 
 static int stagger_ticks() {
@@ -2014,8 +2052,10 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
 
     double* ws[2] = {static_cast<double*>(d_workspace), static_cast<double*>(d_workspace) + node_bytes / 16};
     const size_t cy = (size_t)S * CSC_TILE_COLS * CSC_TILE_ROWS;
-    _Float16* c0h = gram ? reinterpret_cast<_Float16*>(static_cast<char*>(d_workspace) + node_bytes) : nullptr;
-    double* ynorm2 = gram ? reinterpret_cast<double*>(static_cast<char*>(d_workspace) + node_bytes + cy * 2) : nullptr;
+    char* gws = static_cast<char*>(d_workspace) + node_bytes;
+    _Float16* c0h = gram ? reinterpret_cast<_Float16*>(gws) : nullptr;
+    double* ynorm2 = gram ? reinterpret_cast<double*>(gws + cy * 2) : nullptr;
+
     if (gram) hipFuncSetAttribute((const void*)mmp_level_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
     hipStream_t st = (hipStream_t)stream;
