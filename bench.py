@@ -14,13 +14,15 @@ already resident in HBM; with N > 1 every rank holds its own 3200 signals (weak 
 step ends with the ONE gather of the fixed-size sparVar records on rank 0 over RCCL.
 
 Reported next to `value`:
-  roofline      memory roofline of the dominant kernel (mmp_level_kernel), launch durations measured
-                live with HIP events on the launch stream (csc_timer in include/csc_hip.h).  Level 0
-                correlates on fp32 MFMA; deeper nodes read the signal's correlations and one slice of the
-                atom cross-correlation table per ancestor (algorithmic bytes: DESIGN.md section 4).
-  mfma_path     the same batch with every node multiplied on the matrix cores, against the fp32 MFMA
-                peak: algorithmic flops per signal = n_sel * 2*P*K*L, n_sel = 13 (dense semantics of the
-                reference, zero padding of the atoms NOT discounted).
+  roofline      matrix-core roofline of the dominant kernel (mmp_level_kernel), launch durations measured
+                live with HIP events on the launch stream (csc_timer in include/csc_hip.h).  A node's
+                correlations are taken on the fp16 matrix cores as a filter and the entries in its rounding
+                band are re-scored in float64: algorithmic flops per signal = n_sel * 2*P*K*L, n_sel = 13
+                (dense semantics of the reference, the atoms' zero padding NOT discounted), against the dense
+                fp16 MFMA peak; the same figure against the fp32 MFMA peak of BASELINE.json's metric is
+                given beside it.
+  fp32_path     the same batch with CSC_FLAG_FP32_ONLY (every node correlated on v_mfma_f32_16x16x4_f32, the
+                path BASELINE.json's north star describes), against the fp32 MFMA peak; identical records.
   cpu_baseline  the oracle's reference-faithful mode (oaconvolve over all atoms + lsqr defaults + one
                 fresh tree per sparsity = the reference's cost structure; kind "port" because the
                 reference's files cannot travel to the GPU box) on a bounded sample, rank 0, N = 1 only.
@@ -42,7 +44,7 @@ CONNECTIONS, BRANCHES, MAX_SPARSITY, DISSIMILARITY = 3, 3, 5, 0.8
 SIGNAL_LENGTH, PER_CELL = 738, 200
 SNR_LEVELS, SPARSITY_LEVELS = [0, 5, 10, 15], [2, 3, 4, 5]
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-HBM_PEAK_GBS = 8000.0              # same guide, "HBM3E peak BW" (spec); 6.29 TB/s measured copy rate
+FP16_MFMA_PEAK_TFLOPS = 2500.0     # same guide, "Peak BF16/FP16 MFMA": ~2.5 PF dense
 CPU_SAMPLE = [i * PER_CELL + 7 for i in (0, 3, 5, 6, 9, 10, 12, 15)]   # one signal in 8 of the 16 cells
 
 
@@ -107,7 +109,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--per-cell", type=int, default=PER_CELL, help="signals per (snr, sparsity) cell per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-mfma-leg", action="store_true", help="skip the all-MFMA comparison run (profiling)")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-only comparison run (profiling)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -189,11 +191,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # the same batch with every node correlated on the matrix cores (no cross-correlation table): the
-    # "% of fp32 MFMA peak" leg of BASELINE.json's metric; outside the timed region, no collective
-    spans_m, mfma_elapsed, msteps, same = [], 0.0, 0, None
-    if not a.no_mfma_leg:
-        bank.use_gram = False
+    # the same batch correlated in fp32 only (CSC_FLAG_FP32_ONLY): the "% of fp32 MFMA peak" leg of
+    # BASELINE.json's metric; outside the timed region, no collective
+    spans_m, fp32_elapsed, msteps, same = [], 0.0, 0, None
+    if not a.no_fp32_leg:
+        bank.fp32_only = True
         out_m = bank.mmpdf_launch(d_sig, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY, want_coef=False)
         torch.cuda.synchronize(dev)
         msteps = max(2, min(5, a.steps))
@@ -203,10 +205,10 @@ def main():
             for _ in range(msteps):
                 bank.mmpdf_launch(d_sig, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY, want_coef=False, out=out_m)
             torch.cuda.synchronize(dev)
-        mfma_elapsed = time.perf_counter() - t0
+        fp32_elapsed = time.perf_counter() - t0
         spans_m = timer_m.read()
         timer_m.close()
-        bank.use_gram = True
+        bank.fp32_only = False
         same = bool(torch.equal(out_m["rec_buf"], out["rec_buf"]))
 
     if rank == 0:
@@ -214,39 +216,34 @@ def main():
         value = world * S * a.steps / elapsed
         launch_ms = float(np.mean([ms for _, ms in spans]))
         per_level = {str(d): float(np.mean([ms for lv, ms in spans if lv == d])) for d in range(MAX_SPARSITY)}
-        # ---- algorithmic bytes of the default path: level 0 multiplies and keeps the
-        # signal's correlations C_y (K*P f32); a selecting node at depth d >= 1 reads C_y and d slices of the
-        # atom cross-correlation table (K*P f32 each) plus its workspace entry (residual + factor + coefficients)
-        KP4 = K * P * 4.0
-        node_ws = (N + MAX_SPARSITY * (MAX_SPARSITY + 1) // 2 + MAX_SPARSITY) * 8.0
-        bytes_per_signal = N * 8.0 + KP4 + sum(sizes[d - 1] * ((1 + d) * KP4 + 2 * node_ws)
-                                               for d in range(1, MAX_SPARSITY))
-        bytes_per_launch = S * bytes_per_signal / MAX_SPARSITY
-        achieved_gbs = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        dense_tflops = S * flops_per_signal / MAX_SPARSITY / (launch_ms * 1e-3) / 1e12
-        # ---- MFMA leg ---------------------------------------------------------------------------------------
-        mfma_path = None
+        # ---- algorithmic flops: every selecting node correlates its residual with all
+        # K atoms at all P shifts, 2*P*K*L flops, n_sel = 13 nodes per signal over the 5 level launches
+        flops_per_launch = S * flops_per_signal / MAX_SPARSITY
+        achieved = flops_per_launch / (launch_ms * 1e-3) / 1e12
+        # MFMA flops actually issued by the fp16 filter: every (32-row x 16-atom) bank block, 4 waves x 4
+        # v_mfma_f32_16x16x32_f16 (16384 flop each) per node
+        nslab = (L + 31) // 32
+        issued16 = S * n_sel * nslab * 9 * 4 * 4 * 16384.0 / MAX_SPARSITY / (launch_ms * 1e-3) / 1e12
+        fp32_path = None
         if spans_m:
             launch_ms_m = float(np.mean([ms for _, ms in spans_m]))
-            flops_per_launch = S * flops_per_signal / MAX_SPARSITY   # 5 level launches share n_sel nodes
-            achieved = flops_per_launch / (launch_ms_m * 1e-3) / 1e12
-            # MFMA flops actually issued: (32-row x 16-atom) blocks holding only the atoms' zero padding are
-            # skipped, every other block costs 4 waves x 32 v_mfma_f32_16x16x4_f32 (2048 flop each) per node
-            meta = bank.bank32t[-208:].view(torch.int32).cpu().numpy()
-            nslab = (L + 31) // 32
+            achieved_m = flops_per_launch / (launch_ms_m * 1e-3) / 1e12
+            # fp32 MFMA flops issued: blocks holding only the atoms' zero padding are skipped, every other
+            # block costs 4 waves x 32 v_mfma_f32_16x16x4_f32 (2048 flop each) per node
+            off = nslab * 9 * 512
+            meta = bank.bank32t[off:off + 208].view(torch.int32).cpu().numpy()
             blocks = sum(9 - (int(m) & -int(m)).bit_length() + 1 for m in meta[144:144 + nslab] if m)
             issued = S * n_sel * blocks * 4 * 32 * 2048.0 / MAX_SPARSITY / (launch_ms_m * 1e-3) / 1e12
-            mfma_path = {
-                "note": "same batch with the table disabled: every node correlates its residual on the matrix "
-                        "cores (DeviceBank.use_gram = False); identical records: %s" % same,
-                "value": S * msteps / mfma_elapsed, "unit": "signals/s",
-                "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-                             "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+            fp32_path = {
+                "note": "same batch with CSC_FLAG_FP32_ONLY: every node correlates its residual on "
+                        "v_mfma_f32_16x16x4_f32 (DeviceBank.fp32_only = True); identical records: %s" % same,
+                "value": S * msteps / fp32_elapsed, "unit": "signals/s",
+                "roofline": {"bound": "mfma", "achieved": achieved_m, "peak": FP32_MFMA_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": achieved_m / FP32_MFMA_PEAK_TFLOPS,
                              "launch_ms_avg": launch_ms_m,
                              "launch_ms_by_level": {str(d): float(np.mean([ms for lv, ms in spans_m if lv == d]))
                                                     for d in range(MAX_SPARSITY)},
                              "flops_per_launch": flops_per_launch,
-                             "flops_per_signal": flops_per_signal,
                              "mfma_issued": {"tflops": issued, "frac_of_peak": issued / FP32_MFMA_PEAK_TFLOPS,
                                              "blocks_per_node": blocks, "of_dense_blocks": nslab * 9,
                                              "note": "`achieved` counts the reference's dense 2*P*K*L flops per "
@@ -260,7 +257,7 @@ def main():
         line = {
             "metric": "signals/sec for MMP-DF (3 branches, sparsity<=5)", "value": value, "unit": "signals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
             "data": "synthetic",
             "config": {"workload": "config 2: 3200-signal sparVar sweep (sparsity 2-5 x SNR 0-15 dB, 200 each, "
                                    "constrained), MMP-DF connections 3 / branches 3 / max sparsity 5 / "
@@ -269,24 +266,28 @@ def main():
                        "nodes_per_signal": NN, "parallelism": f"signals sharded over {world} rank(s), "
                                                               "one RCCL gather of the sparVar records per step"
                                                               if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP16_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "mmp_level_kernel", "launch_ms_avg": launch_ms, "launch_ms_by_level": per_level,
-                         "bytes_per_launch": bytes_per_launch, "bytes_per_signal": bytes_per_signal,
+                         "flops_per_launch": flops_per_launch, "flops_per_signal": flops_per_signal,
                          "launches_timed": len(spans),
-                         "note": "level 0 correlates on fp32 MFMA; levels 1-4 (80 % of the time) stream the signal's "
-                                 "correlations and cross-correlation table slices, so the launch average is "
-                                 "memory-bound; the table (42 MB) is served from the Infinity Cache",
-                         "dense_flops_equivalent": {"tflops": dense_tflops,
-                                                    "frac_of_fp32_mfma_peak": dense_tflops / FP32_MFMA_PEAK_TFLOPS,
-                                                    "note": "the reference's 2*P*K*L flops per selecting node, "
-                                                            "had every node been multiplied"}},
-            "mfma_path": mfma_path,
+                         "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "mfma_issued": {"tflops": issued16, "frac_of_peak": issued16 / FP16_MFMA_PEAK_TFLOPS,
+                                         "note": "v_mfma_f32_16x16x32_f16 flops issued by the filter (padding "
+                                                 "blocks included)"},
+                         "note": "correlations on the fp16 matrix cores as a filter (arithmetic dtype f16, fp32 "
+                                 "accumulation), selection decided by a float64 re-score of the entries in the "
+                                 "fp16 rounding band; `achieved` counts the reference's dense 2*P*K*L flops per "
+                                 "selecting node; `traffic` is HBM bytes per launch (rocprofv3 PMC, "
+                                 "profiles/hbm_traffic.json)"},
+            "fp32_path": fp32_path,
             "cpu_baseline": cpu,
             "pcie_inclusive": {"value": S / pcie_s, "unit": "signals/s",
                                "note": "one call: host f64 signals -> HBM, solve, sparVar records -> host",
                                "first_call_s": first_call_s},
             "fp32_argmax_fallbacks": stats[0], "duplicate_columns": stats[1],
+            "rescored_candidates_per_selection": stats[2] / max(1, a.steps + a.warmup + 2) / (S * NN),
+            "nodes_repeated_in_fp32": stats[3] // max(1, a.steps + a.warmup + 2),
         }
         print(json.dumps(line), flush=True)
     if use_dist:

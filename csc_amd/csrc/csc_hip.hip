@@ -42,8 +42,6 @@
 #define KMAX CSC_MAX_SPARSITY
 #define TRI(n) ((n) * ((n) + 1) / 2)
 #define DELTA_REL 6.103515625e-05f      // 2^-14: fp32 candidate band, in units of ||residual||
-#define GRAM_W (2 * CSC_TILE_ROWS)     // shifts per (atom, column) row of the cross-correlation table
-#define GRAM_MAX_DEPTH 2               // deeper nodes: the fp16 matrix-core filter is cheaper than (1 + d) table slices
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte access
@@ -83,19 +81,13 @@ struct LevelArgs {
     int depth;            // level d of the parents expanded by this launch
     int Kmax, connections, NN;
     int NS;               // doubles per node in the workspace: N residual + TRI(Kmax) Cholesky factor + Kmax coefficients
-    int stagger_ticks;    // > 0: initial phase offset between the two workgroups of a CU (100 MHz ticks)
     int mode;             // 0: orthogonal (OMP / MMP-DF least squares); 1: plain matching pursuit
     const double* resid_in;   // d == 0: signals [S][N]; else [S][F[d]][NS]
     double* resid_out;        // [S][F[d+1]][NS] or nullptr (children are final leaves)
     int32_t* node_pos; int32_t* node_atom; double* node_mse; double* node_coef;
     int32_t* stats;
-    const _Float16* gram16;  // atom cross-correlation table in fp16, two copies ([2][K][144][GRAM_W]; copy 1 is
-                          // shifted by one element so that every 4-element window starts dword-aligned), or
-                          // nullptr (every level multiplies)
     const _Float16* bank16;  // the bank in fp16, blocked like bank32t with (k-group, column, 8 rows) fragments
-    const float* amax2;   // max_k ||a_k||^2 (scales the fp16 error bounds; also max |table entry|)
-    _Float16* c0h;        // [S][144][256] f16: correlations of the ORIGINAL signals / ||y||, written by level 0
-    double* ynorm2;       // [S] squared norm of the original signals, written by level 0
+    const float* amax2;   // max_k ||a_k||^2 (scales the fp16 error bound)
     TreeShape ts;
 };
 
@@ -312,9 +304,8 @@ __device__ __forceinline__ void corr_rem_gemm(const float* __restrict__ tile, co
 // (SLABF halves each) at slab16.
 // `first` holds elements tid + 256 u (u < 4) of the window, zero beyond N, still in registers from the prologue
 // (whole window when N <= 1024); longer signals re-read the LDS copy.
-template <bool REGS>
 __device__ __forceinline__ void build_r16(const double* r64, int N, float inv, const double (&first)[4], _Float16* r16) {
-    if (REGS && N <= 4 * WG) {
+    if (N <= 4 * WG) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = threadIdx.x + WG * u;
@@ -534,42 +525,6 @@ __global__ __launch_bounds__(WG) void sim_table_kernel(const double* __restrict_
             if (w0 < W) row[w0] = (uint32_t)m;
             if (w0 + 1 < W) row[w0 + 1] = (uint32_t)(m >> 32);
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// atom cross-correlation table: X[ks][c][dp + P - 1] = sum_j a_k[j] * a_ks[j + dp], k = atom of bank column c
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void gram_table_kernel(const double* __restrict__ bank64,
-                                                        const int32_t* __restrict__ meta, int K, int L, int P,
-                                                        _Float16* __restrict__ gram16) {
-    extern __shared__ double sm[];
-    double* a_sel = sm;            // [L]
-    double* a_k = sm + L;          // [L]
-    const int ksel = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
-    const int k = meta[c];
-    // two fp16 copies: h0[j] = X[j], h1[j] = X[j - 1] (so a 4-element window at an odd j starts dword-aligned in h1)
-    _Float16* h0 = gram16 + ((size_t)ksel * CSC_TILE_COLS + c) * GRAM_W;
-    _Float16* h1 = h0 + (size_t)K * CSC_TILE_COLS * GRAM_W;
-    if (k < 0) {                                                     // padding column
-        for (int i = tid; i < GRAM_W; i += WG) { h0[i] = (_Float16)0.f; h1[i] = (_Float16)0.f; }
-        return;
-    }
-    for (int i = tid; i < L; i += WG) {
-        a_sel[i] = bank64[(size_t)ksel * L + i];
-        a_k[i] = bank64[(size_t)k * L + i];
-    }
-    __syncthreads();
-    for (int dpi = tid; dpi < GRAM_W; dpi += WG) {
-        double acc = 0.0;
-        if (dpi < 2 * P - 1) {
-            const int dp = dpi - (P - 1);
-            const int j0 = max(0, -dp), j1 = min(L, L - dp);
-            for (int j = j0; j < j1; ++j) acc = fma(a_k[j], a_sel[j + dp], acc);
-        }
-        h0[dpi] = (_Float16)(float)acc;
-        if (dpi + 1 < GRAM_W) h1[dpi + 1] = (_Float16)(float)acc;
-        if (dpi == 0) h1[0] = (_Float16)0.f;
     }
 }
 
@@ -1032,104 +987,14 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
     PROF_MARK(8);
 }
 
-// ---- the correlations of a node held in registers: two layouts -------------------------------------------
-// f32x4 acc[MT][NT] (144 values per lane) holds the (256 positions x 144 bank columns) correlation tile.
-//   MFMA layout (ROWS = false, GEMM nodes): what v_mfma_f32_16x16x4 leaves behind,
-//       position 64*wave + 16*mi + 4*(lane>>4) + rg, bank column 16*ni + (lane&15)
-//   row layout (ROWS = true, table nodes): a wave instruction covers one whole bank column,
-//       position 4*lane + rg, bank column 36*wave + 9*mi + ni
-//     so every table load is one contiguous kilobyte (the MFMA layout touches 16 rows of 64 bytes each).
-template <bool ROWS>
-__device__ __forceinline__ int entry_pos(int mi, int rg) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    return ROWS ? 4 * lane + rg : 64 * wave + 16 * mi + 4 * (lane >> 4) + rg;
-}
-template <bool ROWS>
-__device__ __forceinline__ int entry_col(int mi, int ni) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    return ROWS ? 36 * wave + NT * mi + ni : 16 * ni + (lane & 15);
-}
+// ---- the correlations of a node held in registers --------------------------------------------------------
+// f32x4 acc[MT][NT] (144 values per lane) holds the (256 positions x 144 bank columns) correlation tile as the
+// 16x16 MFMAs leave it: position 64*wave + 16*mi + 4*(lane>>4) + rg, bank column 16*ni + (lane&15).
 
-// Nine table columns (one mi row of acc) per batch, two batches in flight.  pin() makes the nine loaded vectors
-// live at one point, so the nine loads are issued back to back and waited for once: left to itself the
-// compiler, short of registers next to the 144 accumulators, issues one load at a time with a full
-// s_waitcnt after each, and the table path then runs at the latency, not the bandwidth, of the memory.
-template <typename V>
-__device__ __forceinline__ void pin(V (&b)[NT]) {
-    asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]),
-                      "+v"(b[7]), "+v"(b[8]));
-}
-template <typename VU, typename V, typename T>
-__device__ __forceinline__ void load_cols(const T* gp, int mi, V (&b)[NT]) {
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) b[ni] = *reinterpret_cast<const VU*>(gp + (NT * mi + ni) * GRAM_W);
-}
-__device__ __forceinline__ void sub_cols(f32x4 (&acc)[NT], float ci, const f32x4 (&b)[NT]) {
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) acc[ni] -= ci * b[ni];
-}
-__device__ __forceinline__ void sub_cols(f32x4 (&acc)[NT], float ci, const f16x4 (&b)[NT]) {
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) acc[ni] -= ci * __builtin_convertvector(b[ni], f32x4);
-}
-
-// row layout from the fp16 tables, in units of ||y||: acc = C_y/||y|| - sum_i (c_i/||y||) X_i
-__device__ __forceinline__ void fill_from_tables16(const LevelArgs& a, const NodeLds* sl, size_t s, int d, int P,
-                                                   float ynorm, f32x4 (&acc)[MT][NT]) {
+// entries outside the (P x K) matrix never win: positions >= P (last row tile only) and padding columns
+__device__ __forceinline__ void mask_outside(f32x4 (&acc)[MT][NT], const int (&permv)[NT], int P) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const _Float16* c0p = a.c0h + ((size_t)s * CSC_TILE_COLS + 36 * wave) * CSC_TILE_ROWS + 4 * lane;
-    const float inv = 1.f / ynorm;
-    const size_t copy = (size_t)a.K * CSC_TILE_COLS * GRAM_W;        // elements of one fp16 copy
-    const size_t astride = (size_t)CSC_TILE_COLS * GRAM_W;
-    const _Float16* gbase = a.gram16 + (size_t)36 * wave * GRAM_W;
-    // element j0 = 4*lane + P - 1 - p_i of the slice; copy (j0 & 1) holds X shifted by (j0 & 1): 4-byte aligned
-    auto slice = [&](int i) {
-        const int j0 = 4 * lane + P - 1 - sl->sup_pos[i], par = j0 & 1;       // par is block-uniform
-        return gbase + par * copy + sl->sup_atom[i] * astride + j0 + par;
-    };
-    f16x4 A[NT], B[NT];
-    const _Float16* gp = slice(0);                                   // d >= 1
-    load_cols<f16x4u>(gp, 0, A);
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni)
-            acc[mi][ni] = __builtin_convertvector(
-                *reinterpret_cast<const f16x4*>(c0p + (NT * mi + ni) * CSC_TILE_ROWS), f32x4);
-    for (int i = 0; i < d; ++i) {
-        const float ci = (float)sl->coefpar[i] * inv;
-        const _Float16* gpn = slice(min(i + 1, d - 1));
-        load_cols<f16x4u>(gp, 1, B);  pin(A); sub_cols(acc[0], ci, A);
-        load_cols<f16x4u>(gp, 2, A);  pin(B); sub_cols(acc[1], ci, B);
-        load_cols<f16x4u>(gp, 3, B);  pin(A); sub_cols(acc[2], ci, A);
-        load_cols<f16x4u>(gpn, 0, A); pin(B); sub_cols(acc[3], ci, B);
-        gp = gpn;
-    }
-}
-
-// entries outside the (P x K) matrix never win: positions >= P and padding columns
-template <bool ROWS>
-__device__ __forceinline__ void mask_outside(const NodeLds* sl, f32x4 (&acc)[MT][NT], const int (&permv)[NT], int P) {
-    const int wave = threadIdx.x >> 6;
-    if (ROWS) {
-        if (entry_pos<true>(0, 3) >= P) {
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg)
-                        if (entry_pos<true>(mi, rg) >= P) acc[mi][ni][rg] = -INFINITY;
-        }
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni)
-                if (sl->perm[entry_col<true>(mi, ni)] < 0)           // wave-uniform
-                    acc[mi][ni] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        return;
-    }
-    const int prow = entry_pos<false>(0, 0);
+    const int prow = 64 * wave + 4 * (lane >> 4);
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
         if (64 * wave + 16 * mi + 15 >= P) {                         // wave-uniform
@@ -1153,74 +1018,55 @@ __device__ __forceinline__ void mask_outside(const NodeLds* sl, f32x4 (&acc)[MT]
 // multiply-by-zero suppression of the similarity disk of the placed atom (p_sel, k_sel), src/csc/mmp.py:214-218:
 // the atom's bit row of the similarity table is staged in LDS (aliasing the slab buffers), hit entries become
 // the value-0 marker.  Contains a barrier.
-template <bool ROWS>
 __device__ __forceinline__ void suppress_similar(const LevelArgs& a, NodeLds* sl, uint32_t* simrow, int p_sel, int k_sel,
                                                  const int (&permv)[NT], f32x4 (&acc)[MT][NT], bool& lane_supp) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int W = a.W, W1 = a.W + 1, K = a.K, P = a.P;               // LDS rows padded by one word
     const uint32_t* g = a.sim_bits + (size_t)k_sel * K * W;
     __syncthreads();
     for (int i = tid; i < K * W; i += WG) simrow[(i / W) * W1 + (i % W)] = g[i];
     __syncthreads();
-    const int dp0 = entry_pos<ROWS>(0, 0) - p_sel + P - 1;           // + 16*mi + rg (MFMA) / + rg (rows): bit index
+    const int dp0 = 64 * wave + 4 * (lane >> 4) - p_sel + P - 1;     // + 16*mi + rg: bit index of this entry
     bool any = false;
-    if (ROWS) {
-        // this lane's four positions are four consecutive bits of the column's row: two words, one shift
-        const int w0 = min(dp0 >> 5, W - 1), w1 = min(w0 + 1, W - 1), sh = dp0 & 31;
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const uint32_t* row = simrow + max(permv[ni], 0) * W1;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
-                const uint32_t* row = simrow + max(sl->perm[entry_col<true>(mi, ni)], 0) * W1;   // wave-uniform
-                const uint64_t ww = ((uint64_t)row[w1] << 32) | row[w0];
-                const uint32_t bits = (uint32_t)(ww >> sh) & 15u;
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const bool hit = ((bits >> rg) & 1u) && acc[mi][ni][rg] > -INFINITY;
-                    acc[mi][ni][rg] = hit ? __uint_as_float(SUPP_BITS) : acc[mi][ni][rg];
-                    any |= hit;
-                }
+            for (int rg = 0; rg < 4; ++rg) {
+                const int dpi = dp0 + 16 * mi + rg;
+                const bool hit = ((row[dpi >> 5] >> (dpi & 31)) & 1u) && acc[mi][ni][rg] > -INFINITY;
+                acc[mi][ni][rg] = hit ? __uint_as_float(SUPP_BITS) : acc[mi][ni][rg];
+                any |= hit;
             }
-    } else {
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) {
-            const uint32_t* row = simrow + max(permv[ni], 0) * W1;
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int dpi = dp0 + 16 * mi + rg;
-                    const bool hit = ((row[dpi >> 5] >> (dpi & 31)) & 1u) && acc[mi][ni][rg] > -INFINITY;
-                    acc[mi][ni][rg] = hit ? __uint_as_float(SUPP_BITS) : acc[mi][ni][rg];
-                    any |= hit;
-                }
-        }
     }
     lane_supp |= any;
 }
 
 // Selection of the node's children + their least squares, on the correlations held in acc
 // (reference src/csc/mmp.py:210-231 and :61-70).  `band` is the width below the maximum inside which an entry
-// may be the float64 maximum: every such entry is re-scored in float64.  ROWS: row layout (table nodes).
-// EXACT = false: acc comes from an fp16 filter (wide band); returns false if the node cannot be settled that way
+// may be the float64 maximum: every such entry is re-scored in float64.
+// EXACT = false: acc comes from the fp16 filter (wide band); returns false if the node cannot be settled that way
 // (more than CAND_CAP entries in the band, or the value 0 of suppressed entries inside it): the caller then
-// repeats the node from the start on more exact correlations, with identical results.
-template <bool ROWS, bool EXACT>
+// repeats the node from the start on the fp32 correlations, with identical results.
+template <bool EXACT>
 __device__ __forceinline__ bool select_children(const LevelArgs& a, NodeLds* sl, const double* r64, uint32_t* simrow,
                                                 size_t s, int j, int nch, float band, f32x4 (&acc)[MT][NT]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15;
     const int K = a.K, P = a.P, d = a.depth;
     const int stride = a.ts.pw[d];
-    int permv[NT];                                // MFMA layout: atom of this lane's column in tile ni (-1 = padding)
+    const int prow = 64 * wave + 4 * (lane >> 4);  // + 16*mi + rg: position of an entry
+    int permv[NT];                                // atom of this lane's column in tile ni (-1 = padding)
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) permv[ni] = ROWS ? 0 : sl->perm[16 * ni + lr];
-    mask_outside<ROWS>(sl, acc, permv, P);
+    for (int ni = 0; ni < NT; ++ni) permv[ni] = sl->perm[16 * ni + lr];
+    mask_outside(acc, permv, P);
 
     bool lane_supp = false;                       // this lane holds a suppressed (value 0) entry
     for (int t = 0; t < nch; ++t) {
         // multiply-by-zero suppression by the sibling selected last
-        if (t > 0) suppress_similar<ROWS>(a, sl, simrow, sl->sup_pos[d], sl->sup_atom[d], permv, acc, lane_supp);
+        if (t > 0) suppress_similar(a, sl, simrow, sl->sup_pos[d], sl->sup_atom[d], permv, acc, lane_supp);
         __syncthreads();
         PROF_MARK(2);
         // (a) fp32 maximum.  Suppressed entries carry a quiet NaN, which fmaxf (maxNum) skips; their
@@ -1266,7 +1112,7 @@ __device__ __forceinline__ bool select_children(const LevelArgs& a, NodeLds* sl,
                     const int e = 32 * w + __builtin_ctz(mm);
                     mm &= mm - 1;
                     const int r = e / NT, ni = e - r * NT;
-                    const int idx = entry_pos<ROWS>(r >> 2, r & 3) * Kb + sl->perm[entry_col<ROWS>(r >> 2, ni)];
+                    const int idx = (prow + 16 * (r >> 2) + (r & 3)) * Kb + sl->perm[16 * ni + lr];
                     const int slot = atomicAdd(&sl->cand_cnt, 1);
                     if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
                 }
@@ -1281,8 +1127,7 @@ __device__ __forceinline__ bool select_children(const LevelArgs& a, NodeLds* sl,
 #pragma unroll
                     for (int ni = 0; ni < NT; ++ni)
                         if (is_supp(acc[mi][ni][rg]))
-                            first_supp = min(first_supp, entry_pos<ROWS>(mi, rg) * Kb +
-                                                         (ROWS ? sl->perm[entry_col<true>(mi, ni)] : permv[ni]));
+                            first_supp = min(first_supp, (prow + 16 * mi + rg) * Kb + permv[ni]);
             first_supp = wave_min(first_supp);
             if (lane == 0) sl->wsupp[wave] = first_supp;
         }
@@ -1301,8 +1146,7 @@ __device__ __forceinline__ bool select_children(const LevelArgs& a, NodeLds* sl,
                     for (int ni = 0; ni < NT; ++ni) {
                         const float x = acc[mi][ni][rg];
                         const float e = is_supp(x) ? 0.f : x;
-                        if (e == m32) bi = min(bi, entry_pos<ROWS>(mi, rg) * Kb +
-                                                   (ROWS ? sl->perm[entry_col<true>(mi, ni)] : permv[ni]));
+                        if (e == m32) bi = min(bi, (prow + 16 * mi + rg) * Kb + permv[ni]);
                     }
             bi = wave_min(bi);
             if (lane == 0) sl->widx[wave] = bi;
@@ -1326,48 +1170,17 @@ __device__ __forceinline__ int children_of(const LevelArgs& a, int j) {
     return nch;
 }
 
-// Level 0 keeps the signal's correlations, divided by ||y||, in fp16 for the table nodes of the levels below.
-// Each wave turns its (64 positions x 16 columns) pieces through LDS (tp: 4 x 16 x 72 halves, free after the
-// GEMM) so that a store instruction writes eight whole 128-byte lines; straight from the MFMA layout it would
-// write 16 x 32-byte fragments.
-__device__ __forceinline__ void store_c0h(const LevelArgs& a, size_t s, float scale, _Float16* tp0,
-                                          const f32x4 (&acc)[MT][NT]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lr = lane & 15, lq = lane >> 4;
-    __syncthreads();                                                 // every wave is done with the slab buffers
-    _Float16* tp = tp0 + wave * (16 * 72);                           // [16 columns][64 + 8]
-    _Float16* dst = a.c0h + (size_t)s * CSC_TILE_COLS * CSC_TILE_ROWS + 64 * wave + 8 * (lane & 7);
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-            *reinterpret_cast<f16x4*>(tp + lr * 72 + 16 * mi + 4 * lq) =
-                __builtin_convertvector(acc[mi][ni] * scale, f16x4);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int col = (lane >> 3) + 8 * h;
-            const uint4 v = *reinterpret_cast<const uint4*>(tp + col * 72 + 8 * (lane & 7));
-            *reinterpret_cast<uint4*>(dst + (size_t)(16 * ni + col) * CSC_TILE_ROWS) = v;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 // ---- the level kernel ---------------------------------------------------------------------------------------
-// One workgroup per node of the level.  TABLES = false: the correlations of the node's residual are multiplied on
-// the matrix cores (level 0, dictionaries without a table, very deep levels).
+// One workgroup per node of the level: correlations of the node's residual with every shifted atom on the
+// matrix cores, the children's selection on the register-resident result, their least squares.
 //
-// TABLES = true (levels >= 1): with r = y - sum_i c_i a_i(. - p_i),
-//     C_r[p, k] = C_y[p, k] - sum_i c_i X[k_i][k][p - p_i],   X = atom cross-correlations (csc_gram_table),
-// so a node's correlations are the signal's (kept by level 0) minus d table slices.  Both operands are held in
-// fp16 (C_y / ||y||, and X): the node streams (1 + d) x 74 KB instead of multiplying, and what it gets is only a
-// FILTER: every entry within twice the fp16 error bound of the computed maximum (a handful, rarely a few
-// dozen) is re-scored in float64 against the residual, exactly as the GEMM path re-scores its fp32 band, so the
-// selection is the float64 arg-max either way.  A node this cannot settle multiplies after all, in the same
-// workgroup: a collapsed residual (||r|| < ||y|| / 64, the error bound would swamp its correlations), more than
-// CAND_CAP entries in the band, the value 0 of suppressed entries inside the band, NaN / Inf / extreme scales.
-template <bool TABLES>
+// The correlations are first taken in fp16 (v_mfma_f32_16x16x32_f16, 16x the fp32 rate) from the residual scaled
+// to unit norm.  That product is only a FILTER: every entry within twice the fp16 rounding bound of the computed
+// maximum (typically 5-15 entries) is re-scored in float64 against the residual, so the selection is the
+// float64 arg-max, as it is when the fp32 product is re-scored over its own (narrow) band.  A node the filter
+// cannot settle -- more than CAND_CAP entries in the band, the value 0 of suppressed entries inside the band,
+// NaN / Inf / extreme scales -- multiplies again in fp32 (v_mfma_f32_16x16x4_f32) in the same workgroup and
+// repeats the selection from the start, with identical results.
 __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     extern __shared__ double lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1377,7 +1190,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     // ---- LDS carve-up ---------------------------------------------------------------------------
     const int Npad = (N + 3) & ~3;
     const int R32 = CSC_TILE_ROWS + Lp + 4;
-    float* slab = reinterpret_cast<float*>(lds_raw);                  // [2][SLABF]
+    float* slab = reinterpret_cast<float*>(lds_raw);                  // [2][SLABF] floats = [RING16][SLABF] halves
     uint32_t* simrow = reinterpret_cast<uint32_t*>(slab);             // aliases the slabs
     double* r64 = lds_raw + SLABF;                                    // [Npad]   (2*SLABF floats = SLABF doubles)
     float* r32 = reinterpret_cast<float*>(r64 + Npad);                // [R32]
@@ -1392,85 +1205,39 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
     if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
 
-    PROF_INIT(TABLES ? 16 : 0);
+    PROF_INIT(0);
     const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
     double rnorm2, first[4];
     const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2, first);
     PROF_MARK(0);
     f32x4 acc[MT][NT];
-    // fp16 rounding bounds, relative to ||a|| ||r|| with the norms taken as 1 (see the callers' scaling):
-    //   E_MFMA16: both operands rounded (2 x 2^-11), fp32 accumulation over L terms (2^-14), cross terms
-    //   E_SUB:    absolute 2^-25 per operand that is subnormal in fp16, summed over a window (sqrt(L) each side)
-    const float am2 = *a.amax2, am = sqrtf(am2);
-    const float E_MFMA16 = 9.765625e-04f + DELTA_REL + 1e-6f;
-    const float E_SUB = 2.9802322e-08f * sqrtf((float)L) * (1.f + am);
-    const bool amax_ok = am2 > 1e-6f && am2 < 1e4f;
-    if (TABLES) {
-        const double y2 = a.ynorm2[s];
-        if (amax_ok && y2 > 1e-30 && y2 < 1e30 && rnorm2 * 4096.0 >= y2) {
-            float csum = 0.f;
-            for (int i = 0; i < d; ++i) csum += fabsf((float)sl->coefpar[i]);
-            const float ynorm = (float)sqrt(y2);
-            // Error of an entry of acc, in units of ||y||: C_y / ||y|| carries the level-0 fp16 MFMA bound plus
-            // its own rounding to fp16 (2^-11), |C_y| <= ||y|| am; every table entry is rounded by 2^-11
-            // (2^-25 absolute when subnormal), |X| <= am2; the fp32 arithmetic here adds (d + 1) 2^-23.
-            // An entry that can be the float64 maximum lies within twice that of the computed maximum.
-            const float cr = csum / ynorm;
-            const float eps = (E_MFMA16 + 4.8828125e-04f) * am + E_SUB + (4.8828125e-04f + 1e-6f) * am2 * cr +
-                              2.9802322e-08f * (1.f + cr);
-            fill_from_tables16(a, sl, s, d, a.P, ynorm, acc);
-            PROF_MARK(1);
-            if (select_children<true, false>(a, sl, r64, simrow, s, j, nch, 2.f * eps, acc)) {
-                PROF_MARK(9);
-                return;
-            }
-            if (tid == 0 && a.stats) atomicAdd(&a.stats[3], 1);
-        }
-        PROF_INIT(0);                                                // what follows counts as a GEMM node
-    }
     // ---- correlations on the fp16 matrix cores, in units of ||r||, as a filter ------------------------------
-    const bool filter16 = a.bank16 && amax_ok && rnorm2 > 1e-30 && rnorm2 < 1e30;
-    bool stored = false;
-    if (filter16) {
-        _Float16* ring = reinterpret_cast<_Float16*>(slab);                   // [RING16][SLABF] halves = the slab area
-        build_r16<!TABLES>(r64, N, (float)(1.0 / sqrt(rnorm2)), first, r16);   // table nodes rarely get here
-        __syncthreads();                                                      // r16 built; simrow (ring's LDS) no longer read
+    // Rounding bound of an entry, with am = max_k ||a_k||:
+    //   both operands rounded to fp16 (2 x 2^-11 relative), fp32 accumulation over L terms (2^-14), cross terms:
+    //       (2^-10 + 2^-14 + 2^-20) am
+    //   an operand that is subnormal in fp16 is off by up to 2^-25 absolute instead, over a window of L terms:
+    //       2^-25 sqrt(L) (1 + am)
+    const float am2 = *a.amax2, am = sqrtf(am2);
+    const float eps16 = (9.765625e-04f + DELTA_REL + 1e-6f) * am + 2.9802322e-08f * sqrtf((float)L) * (1.f + am);
+    if (a.bank16 && am2 > 1e-6f && am2 < 1e4f && rnorm2 > 1e-30 && rnorm2 < 1e30) {
+        _Float16* ring = reinterpret_cast<_Float16*>(slab);
+        build_r16(r64, N, (float)(1.0 / sqrt(rnorm2)), first, r16);
+        __syncthreads();
         corr_tile_gemm16(a.bank16, sl->masks, (L + SLAB - 1) / SLAB, r16, ring, acc);
-        if (!TABLES && d == 0 && a.c0h) {
-            store_c0h(a, s, 1.f, reinterpret_cast<_Float16*>(slab), acc);
-            if (tid == 0) a.ynorm2[s] = rnorm2;
-            stored = true;
-        }
         PROF_MARK(1);
-        if (select_children<false, false>(a, sl, r64, simrow, s, j, nch, 2.f * (E_MFMA16 * am + E_SUB), acc)) {
+        if (select_children<false>(a, sl, r64, simrow, s, j, nch, 2.f * eps16, acc)) {
             __syncthreads();
             PROF_MARK(9);
             return;
         }
         if (tid == 0 && a.stats) atomicAdd(&a.stats[3], 1);
         __syncthreads();
+        PROF_INIT(16);                                               // what follows is counted apart
     }
     // ---- correlations on the fp32 matrix cores ------------------------------------------------------
     corr_tile_gemm(a.bank32t, sl->masks, (L + SLAB - 1) / SLAB, r32 + 64 * wave + lr + lq, slab, acc);
-    if (!TABLES && d == 0 && a.c0h && !stored) {
-        store_c0h(a, s, rnorm2 > 0.0 ? (float)(1.0 / sqrt(rnorm2)) : 0.f, reinterpret_cast<_Float16*>(slab), acc);
-        if (tid == 0) a.ynorm2[s] = rnorm2;
-    }
     PROF_MARK(1);
-#ifdef CSC_PHASE_PROF
-    if (a.stagger_ticks == -7) {              // development aid: GEMM only (CSC_GEMM_ONLY)
-        float lm = -INFINITY;
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) lm = fmaxf(lm, acc[mi][ni][rg]);
-        if (lm == 12345.f) a.node_mse[0] = lm;
-        return;
-    }
-#endif
-    select_children<false, true>(a, sl, r64, simrow, s, j, nch, delta, acc);
+    select_children<true>(a, sl, r64, simrow, s, j, nch, delta, acc);
     __syncthreads();
     PROF_MARK(9);
 }
@@ -1858,20 +1625,6 @@ static size_t level_lds_bytes(int N, int Lp) {
     return (size_t)Npad * 8 + sizeof(NodeLds) + (size_t)ceil4(R32) * 4 + 2 * SLABF * 4 + R16_COPIES * R16_CS * 2;
 }
 
-static int stagger_ticks() {
-    static int v = -1;
-    if (v == -1) {
-        const char* e = getenv("CSC_STAGGER_US");
-        v = e ? atoi(e) * 100 : 0;                                    // wall_clock64 runs at 100 MHz
-#ifdef CSC_PHASE_PROF
-        if (getenv("CSC_GEMM_ONLY")) v = -7;
-        else
-#endif
-        if (v < 0 || v > 100000) v = 0;
-    }
-    return v;
-}
-
 // ------------------------------------------------------------------------------------------------
 // optional per-launch HIP-event timer (bench.py's live roofline measurement)
 // ------------------------------------------------------------------------------------------------
@@ -1896,7 +1649,7 @@ static inline void timer_end(hipStream_t st, int i) {
 
 extern "C" {
 
-int csc_abi_version(void) { return 2; }
+int csc_abi_version(void) { return CSC_ABI_VERSION; }
 const char* csc_last_error(void) { return g_err; }
 
 size_t csc_bank32_elems(int K, int L) {
@@ -1977,41 +1730,15 @@ static size_t node_ws_bytes(int S, int N, int max_sparsity, const TreeShape& ts)
     return 2 * (size_t)S * fmax * (N + TRI(max_sparsity) + max_sparsity) * sizeof(double);
 }
 
-size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections, int branches, int with_gram) {
+size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections, int branches) {
     TreeShape ts;
     if (make_shape(max_sparsity, connections, branches, &ts) < 0 || S <= 0 || N <= 0) return 0;
-    size_t b = node_ws_bytes(S, N, max_sparsity, ts);
-    if (with_gram) {   // C_y / ||y|| in f16, ||y||^2
-        b += (size_t)S * CSC_TILE_COLS * CSC_TILE_ROWS * 2 + (size_t)S * sizeof(double);
-    }
-    return b;
-}
-
-static size_t gram_halves(int K) { return 2 * (size_t)K * CSC_TILE_COLS * GRAM_W; }    // two fp16 copies
-
-size_t csc_gram_elems(int K, int L, int N) {
-    const int P = N - L + 1;
-    if (K <= 0 || K > CSC_TILE_COLS || P <= 0 || P > CSC_TILE_ROWS) return 0;
-    return gram_halves(K) / 2;                                       // in floats
-}
-
-int csc_gram_table(const double* d_bank64, const float* d_bank32t, int K, int L, int N, float* d_gram,
-                   void* stream) {
-    const int P = N - L + 1;
-    if (!d_bank64 || !d_bank32t || !d_gram || K <= 0 || L <= 0) FAIL(-1, "csc_gram_table: bad arguments");
-    if (csc_gram_elems(K, L, N) == 0)
-        FAIL(-9, "csc_gram_table: needs K <= %d and 1 <= P <= %d (got K = %d, P = %d)", CSC_TILE_COLS,
-             CSC_TILE_ROWS, K, P);
-    clear_stale_error();
-    hipLaunchKernelGGL(gram_table_kernel, dim3(CSC_TILE_COLS, K), dim3(WG), (size_t)2 * L * sizeof(double),
-                       (hipStream_t)stream, d_bank64, bank_meta(d_bank32t, K, L), K, L, P,
-                       reinterpret_cast<_Float16*>(d_gram));
-    return launch_status("gram_table_kernel");
+    return node_ws_bytes(S, N, max_sparsity, ts);
 }
 
 static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
-                      const float* d_gram, int K, int L, const double* d_signals, int S, int N,
-                      int max_sparsity, int connections, int branches,
+                      int K, int L, const double* d_signals, int S, int N,
+                      int max_sparsity, int connections, int branches, int flags,
                       void* d_workspace, size_t workspace_bytes,
                       int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse,
                       double* d_node_coef, double* d_rec_mse, int32_t* d_rec_leaf,
@@ -2032,43 +1759,30 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         FAIL(-9, "dictionary (K = %d, P = %d) exceeds %d (256 x 144) units per node", K, P, MAX_UNITS);
     if (n_slabs(L) > MAX_SLABS) FAIL(-8, "atom length %d exceeds %d", L, MAX_SLABS * SLAB);
     if (max_sparsity > P * K) FAIL(-2, "max_sparsity exceeds the number of activations");
-    const bool gram = d_gram && !tiled && mode == 0 && max_sparsity > 1;
     const size_t node_bytes = node_ws_bytes(S, N, max_sparsity, ts);
-    const size_t need = csc_mmpdf_workspace_bytes(S, N, max_sparsity, connections, branches, gram ? 1 : 0);
+    const size_t need = node_bytes;
     if (max_sparsity > 1 && (workspace_bytes < need || !d_workspace))
         FAIL(-10, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
     const int Lp = n_slabs(L) * SLAB;                      // residual window zero-padded to whole slabs
     const int W = csc_sim_words(N, L);
     size_t lds = level_lds_bytes(N, Lp);
     if (tiled) lds += (size_t)(nrb - 1) * CSC_TILE_ROWS * 4 + sizeof(TiledLds);
-#ifdef CSC_PHASE_PROF
-    if (getenv("CSC_EXTRA_LDS")) lds += (size_t)atoi(getenv("CSC_EXTRA_LDS"));   // force 1 workgroup per CU
-#endif
     if (lds > 150 * 1024) FAIL(-8, "signal too long for the LDS-resident node kernel (%zu B)", lds);
     if (!tiled && (size_t)K * (W + 1) * 4 > 2 * SLABF * 4) FAIL(-8, "similarity row does not fit the slab buffer");
     clear_stale_error();
-    hipFuncSetAttribute(tiled ? (const void*)mmp_level_tiled_kernel : (const void*)mmp_level_kernel<false>,
+    hipFuncSetAttribute(tiled ? (const void*)mmp_level_tiled_kernel : (const void*)mmp_level_kernel,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 
     double* ws[2] = {static_cast<double*>(d_workspace), static_cast<double*>(d_workspace) + node_bytes / 16};
-    const size_t cy = (size_t)S * CSC_TILE_COLS * CSC_TILE_ROWS;
-    char* gws = static_cast<char*>(d_workspace) + node_bytes;
-    _Float16* c0h = gram ? reinterpret_cast<_Float16*>(gws) : nullptr;
-    double* ynorm2 = gram ? reinterpret_cast<double*>(gws + cy * 2) : nullptr;
-
-    if (gram) hipFuncSetAttribute((const void*)mmp_level_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
     hipStream_t st = (hipStream_t)stream;
     for (int d = 0; d < max_sparsity; ++d) {
         LevelArgs a;
         a.bank32t = d_bank32t; a.meta = bank_meta(d_bank32t, K, L); a.bank64 = d_bank64; a.sim_bits = d_sim_bits;
         a.K = K; a.L = L; a.Lp = Lp; a.N = N; a.P = P; a.W = W;
         a.depth = d; a.Kmax = max_sparsity; a.connections = connections; a.NN = NN;
-        a.NS = N + TRI(max_sparsity) + max_sparsity; a.stagger_ticks = stagger_ticks(); a.mode = mode;
-        a.gram16 = gram ? reinterpret_cast<const _Float16*>(d_gram) : nullptr;
-        a.bank16 = (!tiled && !getenv("CSC_NO_FP16_MFMA")) ? bank_tiles16(d_bank32t, K, L) : nullptr;
+        a.NS = N + TRI(max_sparsity) + max_sparsity; a.mode = mode;
+        a.bank16 = (!tiled && !(flags & CSC_FLAG_FP32_ONLY)) ? bank_tiles16(d_bank32t, K, L) : nullptr;
         a.amax2 = bank_amax2(d_bank32t, K, L);
-        a.c0h = c0h; a.ynorm2 = ynorm2;
         a.resid_in = (d == 0) ? d_signals : ws[d & 1];
         a.resid_out = (d + 1 < max_sparsity) ? ws[(d + 1) & 1] : nullptr;
         a.node_pos = d_node_pos; a.node_atom = d_node_atom; a.node_mse = d_node_mse; a.node_coef = d_node_coef;
@@ -2077,9 +1791,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         if (grid > 0x7fffffffULL) FAIL(-11, "batch too large for one launch (%zu workgroups)", grid);
         const int span = timer_begin(st, d);
         if (tiled) hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
-        else if (gram && d >= 1 && d <= GRAM_MAX_DEPTH)
-            hipLaunchKernelGGL(mmp_level_kernel<true>, dim3((unsigned)grid), dim3(WG), lds, st, a);
-        else hipLaunchKernelGGL(mmp_level_kernel<false>, dim3((unsigned)grid), dim3(WG), lds, st, a);
+        else hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
         timer_end(st, span);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) FAIL((int)e, "mmp_level_kernel launch failed at level %d: %s", d, hipGetErrorString(e));
@@ -2095,14 +1807,14 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
 }
 
 int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
-                    const float* d_gram, int K, int L, const double* d_signals, int S, int N,
-                    int max_sparsity, int connections, int branches,
+                    int K, int L, const double* d_signals, int S, int N,
+                    int max_sparsity, int connections, int branches, int flags,
                     void* d_workspace, size_t workspace_bytes,
                     int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse,
                     double* d_node_coef, double* d_rec_mse, int32_t* d_rec_leaf,
                     int32_t* d_rec_sel, int32_t* d_stats, void* stream) {
-    return run_levels(0, d_bank32t, d_bank64, d_sim_bits, d_gram, K, L, d_signals, S, N, max_sparsity, connections,
-                      branches, d_workspace, workspace_bytes, d_node_pos, d_node_atom, d_node_mse, d_node_coef,
+    return run_levels(0, d_bank32t, d_bank64, d_sim_bits, K, L, d_signals, S, N, max_sparsity, connections,
+                      branches, flags, d_workspace, workspace_bytes, d_node_pos, d_node_atom, d_node_mse, d_node_coef,
                       d_rec_mse, d_rec_leaf, d_rec_sel, d_stats, stream);
 }
 
@@ -2111,7 +1823,7 @@ int csc_mp_batch(const float* d_bank32t, const double* d_bank64, int K, int L, c
                  int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse, double* d_node_mask,
                  int32_t* d_stats, void* stream) {
     if (!d_node_mask && S > 0) FAIL(-1, "csc_mp_batch: d_node_mask is required");
-    return run_levels(1, d_bank32t, d_bank64, nullptr, nullptr, K, L, d_signals, S, N, iterations, 1, 1, d_workspace,
+    return run_levels(1, d_bank32t, d_bank64, nullptr, K, L, d_signals, S, N, iterations, 1, 1, 0, d_workspace,
                       workspace_bytes, d_node_pos, d_node_atom, d_node_mse, d_node_mask, nullptr, nullptr,
                       nullptr, d_stats, stream);
 }

@@ -128,10 +128,9 @@ class DeviceBank:
             _lib.check(self.lib.csc_bank_pack(_ptr(self.bank64), self.K, self.L, _ptr(self.bank32t),
                                               _stream(self.device)), "csc_bank_pack")
         self._sim = {}
-        self._gram = {}
-        # levels >= 1 from the atom cross-correlation table instead of a GEMM per node (same results);
-        # set to False to force the MFMA path everywhere
-        self.use_gram = True
+        # correlations on the fp16 matrix cores as a filter in front of the float64 re-score (same results);
+        # set to True to correlate in fp32 only (CSC_FLAG_FP32_ONLY)
+        self.fp32_only = False
 
     def similarity_table(self, N: int, threshold: float):
         key = (int(N), float(threshold))
@@ -146,22 +145,6 @@ class DeviceBank:
                                                          _stream(self.device)), "csc_similarity_table")
             self._sim[key] = bits
         return self._sim[key]
-
-    def gram_table(self, N: int):
-        """Atom cross-correlation table for signals of length N, or None when the dictionary / signal is
-        beyond one register tile (csc_gram_table)."""
-        key = int(N)
-        if key not in self._gram:
-            n = self.lib.csc_gram_elems(self.K, self.L, N)
-            if n == 0:
-                self._gram[key] = None
-            else:
-                with torch.cuda.device(self.device):
-                    g = torch.empty(n, dtype=torch.float32, device=self.device)
-                    _lib.check(self.lib.csc_gram_table(_ptr(self.bank64), _ptr(self.bank32t), self.K, self.L, N,
-                                                       _ptr(g), _stream(self.device)), "csc_gram_table")
-                self._gram[key] = g
-        return self._gram[key]
 
     # ---- batched correlation (computeCorrelations) ------------------------------------------------
     def correlate(self, signals) -> torch.Tensor:
@@ -243,7 +226,7 @@ class DeviceBank:
         I = int(iterations)
         dev = self.device
         with torch.cuda.device(dev):
-            ws_bytes = self.lib.csc_mmpdf_workspace_bytes(max(S, 1), N, I, 1, 1, 0)
+            ws_bytes = self.lib.csc_mmpdf_workspace_bytes(max(S, 1), N, I, 1, 1)
             ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.float64, device=dev)
             pos = torch.zeros((S, I), dtype=torch.int32, device=dev)
             atom = torch.zeros((S, I), dtype=torch.int32, device=dev)
@@ -264,10 +247,9 @@ class DeviceBank:
         sizes, NN = _lib.tree_shape(max_sparsity, connections, branches)
         dev = self.device
         sim = self.similarity_table(N, dissimilarity) if connections > 1 else None
-        gram = self.gram_table(N) if (self.use_gram and max_sparsity > 1) else None
         with torch.cuda.device(dev):
             if out is None:
-                ws_bytes = self.lib.csc_mmpdf_workspace_bytes(S, N, max_sparsity, connections, branches, 1)
+                ws_bytes = self.lib.csc_mmpdf_workspace_bytes(S, N, max_sparsity, connections, branches)
                 K = max_sparsity
                 # the per-sparsity records live in ONE buffer (what the multi-GPU gather sends):
                 # [S][K] f64 mse | [S][K][2] i32 leaf | [S][K][K][2] i32 (pos, atom)
@@ -286,8 +268,8 @@ class DeviceBank:
                     "stats": torch.zeros(4, dtype=torch.int32, device=dev),
                 }
             rc = self.lib.csc_mmpdf_batch(
-                _ptr(self.bank32t), _ptr(self.bank64), _ptr(sim), _ptr(gram), self.K, self.L, _ptr(sig), S, N,
-                max_sparsity, connections, branches, _ptr(out["ws"]), out["ws"].numel() * 8,
+                _ptr(self.bank32t), _ptr(self.bank64), _ptr(sim), self.K, self.L, _ptr(sig), S, N,
+                max_sparsity, connections, branches, 1 if self.fp32_only else 0, _ptr(out["ws"]), out["ws"].numel() * 8,
                 _ptr(out["node_pos"]), _ptr(out["node_atom"]), _ptr(out["node_mse"]), _ptr(out["node_coef"]),
                 _ptr(out["rec_mse"]), _ptr(out["rec_leaf"]), _ptr(out["rec_sel"]), _ptr(out["stats"]),
                 _stream(dev))

@@ -26,11 +26,12 @@
 extern "C" {
 #endif
 
-#define CSC_ABI_VERSION 2
+#define CSC_ABI_VERSION 3
 #define CSC_TILE_COLS 144      /* atoms per column tile of the correlation kernel (9 x 16)   */
 #define CSC_TILE_ROWS 256      /* positions per row tile (4 waves x 4 x 16)                   */
 #define CSC_MAX_SPARSITY 16    /* largest tree depth / support size                           */
 #define CSC_MAX_CONNECTIONS 8  /* largest number of siblings per node                         */
+#define CSC_FLAG_FP32_ONLY 1   /* csc_mmpdf_batch flags: skip the fp16 matrix-core filter      */
 
 int csc_abi_version(void);
 const char* csc_last_error(void);
@@ -42,7 +43,10 @@ int    csc_sim_words(int N, int L);             /* uint32 per (k_sel, k) row of 
 /* Atom-bank materialisation in HBM.  Replaces the per-call rebuild of the atom matrix in
  * src/csc/dictionary.py:390,404 (np.array([atom() for atom in self.atoms])).
  *   d_bank64  [K][L] f64 (row = atom, as getLocalDictionary(), src/csc/dictionary.py:112-113)
- *   d_bank32t [ceil(K/144)][Lp][144] f32, Lp = ceil4(L): time-major, zero padded column tiles. */
+ *   d_bank32t csc_bank32_elems(K, L) floats, opaque to the caller: the bank as MFMA operand blocks in fp32
+ *             ([column tile of 144][slab of 32 rows][16-column block][32][16], columns sorted by support so
+ *             that all-zero blocks can be skipped), the column permutation and block masks, the same blocks
+ *             in fp16 and max_k ||a_k||^2. */
 int csc_bank_pack(const double* d_bank64, int K, int L, float* d_bank32t, void* stream);
 
 /* Atom-vs-dictionary similarity table.  Replaces, for every node, the
@@ -65,23 +69,8 @@ int csc_correlate(const float* d_bank32t, int K, int L, const double* d_signals,
  * (may be NULL) and returns the number of non-root nodes per signal, or a negative error. */
 int csc_tree_nodes(int max_sparsity, int connections, int branches, int* level_sizes);
 
-/* Atom cross-correlation table for the correlation UPDATE of the deeper tree levels (no counterpart in
- * the reference, which re-correlates every residual, src/csc/mmp.py:69): with the node's residual
- * r = y - sum_i c_i a_{k_i}(. - p_i),
- *     C_r[p, k] = C_y[p, k] - sum_i c_i X[k_i][k][p - p_i],   X[ks][k][dp] = sum_j a_k[j] a_ks[j + dp],
- * so only level 0 multiplies; levels >= 1 read the signal's correlations (kept in the workspace) and one
- * table slice per ancestor.  Exactness of the selection is kept by the fp64 re-score of every entry in
- * the (widened) fp32 error band.  Available when the whole correlation matrix fits one register tile:
- * K <= 144 and 1 <= N - L + 1 <= 256; csc_gram_elems returns 0 otherwise.
- *   d_gram: csc_gram_elems floats = [K][144][512] f32 followed by two fp16 copies of the same table
- *   (first pass of the deeper levels at half the bytes; the entries in its error band are re-evaluated
- *   from the f32 table), column order of d_bank32t (csc_bank_pack must have run). */
-size_t csc_gram_elems(int K, int L, int N);
-int csc_gram_table(const double* d_bank64, const float* d_bank32t, int K, int L, int N, float* d_gram,
-                   void* stream);
-
-/* Bytes of scratch csc_mmpdf_batch needs for S signals (with_gram != 0: a d_gram table is passed). */
-size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections, int branches, int with_gram);
+/* Bytes of scratch csc_mmpdf_batch needs for S signals (two generations of node residuals). */
+size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections, int branches);
 
 /* Batched MMP-DF / OMP: all signals x frontier nodes per level, one launch per level.
  * Replaces the joblib fan-out over MMPTree(...).runMMPDF(...) of
@@ -89,8 +78,10 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
  * connections = branches = 1, the omp loops of :492-552, :574-649.
  *
  * Node id of (level d, index j) is off_d + j with off_1 = 0, off_{d+1} = off_d + F_d; NN = total.
- *   d_gram      csc_gram_table output or NULL (NULL: every node correlates its residual on the MFMA
- *               units; the results are identical either way)
+ *   flags       0, or CSC_FLAG_FP32_ONLY: correlate in fp32 only (v_mfma_f32_16x16x4_f32).  By default a
+ *               node's correlations are first taken on the fp16 matrix cores as a filter and every entry
+ *               within the fp16 rounding bound of the maximum is re-scored in float64; the selections are
+ *               the float64 arg-max either way (identical results, the flag exists to check that)
  *   d_signals   [S][N] f64
  *   d_node_pos  [S][NN] int32   selected position of the node      (src/csc/mmp.py:74-76)
  *   d_node_atom [S][NN] int32   selected atom index
@@ -105,11 +96,12 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
  *               leaf, -1 padded                                      (src/csc/mmp.py:257-265)
  *   d_stats     [4] int32 or NULL (must be zeroed by the caller): [0] selections that fell back
  *               to the fp32 arg-max (candidate overflow), [1] re-selected activations (dead Cholesky
- *               columns), [2] number of fp64 re-scored candidates
+ *               columns), [2] number of fp64 re-scored candidates, [3] nodes the fp16 filter could not
+ *               settle (multiplied again in fp32)
  */
 int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
-                    const float* d_gram, int K, int L, const double* d_signals, int S, int N,
-                    int max_sparsity, int connections, int branches,
+                    int K, int L, const double* d_signals, int S, int N,
+                    int max_sparsity, int connections, int branches, int flags,
                     void* d_workspace, size_t workspace_bytes,
                     int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse,
                     double* d_node_coef, double* d_rec_mse, int32_t* d_rec_leaf,
@@ -117,14 +109,14 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
 
 /* Batched plain convolutional matching pursuit.  Replaces CSCDictionary.mp / mpFromDict /
  * mpSparVarFromDict (src/csc/dictionary.py:764-921): per iteration, correlations of the residual
- * (fp32 MFMA + fp64 re-score as in csc_mmpdf_batch), signed arg-max, activation_mask[idx] += <atom, r>,
+ * (matrix cores + fp64 re-score as in csc_mmpdf_batch), signed arg-max, activation_mask[idx] += <atom, r>,
  * residual = signal - conv(mask * mask) -- the reference multiplies the mask by itself (:803), kept.
  * One node per iteration (NN = iterations, node i = state after iteration i + 1):
  *   d_node_pos / d_node_atom [S][iterations]   activation selected at that iteration
  *   d_node_mse  [S][iterations]                mean((signal - approx)^2) after it
  *   d_node_mask [S][iterations][iterations]    mask value per support slot after it (slot q = q-th
  *               selection; a re-selected activation accumulates in its first slot, the later slot is 0)
- *   workspace: csc_mmpdf_workspace_bytes(S, N, iterations, 1, 1, 0) bytes. */
+ *   workspace: csc_mmpdf_workspace_bytes(S, N, iterations, 1, 1) bytes. */
 int csc_mp_batch(const float* d_bank32t, const double* d_bank64, int K, int L, const double* d_signals,
                  int S, int N, int iterations, void* d_workspace, size_t workspace_bytes,
                  int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse, double* d_node_mask,

@@ -8,8 +8,8 @@ from csc_amd import _lib
 dic = bench.canonical_dictionary()
 sig = bench.make_signals(dic, 0)
 bank = dic.device_bank()
-if "--mfma" in sys.argv:            # every level on the matrix cores (no table)
-    bank.use_gram = False
+if "--fp32" in sys.argv:            # fp32 correlations only
+    bank.fp32_only = True
 d = torch.from_numpy(sig).cuda()
 out = bank.mmpdf_launch(d, 5, 3, 3, 0.8, want_coef=False)
 L = _lib.lib()
@@ -19,10 +19,9 @@ bank.mmpdf_launch(d, 5, 3, 3, 0.8, want_coef=False, out=out)
 torch.cuda.synchronize()
 L.csc_prof_read(buf, 1)
 v = np.array(list(buf), dtype=np.float64)
-names = ["prologue", "gemm / table fill", "suppress", "max + candidates", "fp16 band resolve", "rescore + choose",
+names = ["prologue", "gemm", "suppress", "max + candidates", "-", "rescore + choose",
          "gram dots", "solve", "residual + write", "tail"]
-rows = (("mmp_level_kernel (all levels)", 0, 3200 * 13),) if "--mfma" in sys.argv else \
-    (("mmp_level_kernel (level 0)", 0, 3200), ("mmp_level_table_kernel (levels 1-4)", 16, 3200 * 12))
+rows = (("nodes (fp16 filter, or fp32 only)", 0, 3200 * 13), ("nodes repeated in fp32 after the filter", 16, 3200 * 13))
 for title, base, nodes in rows:
     w = v[base:base + 10]
     tot = w.sum()

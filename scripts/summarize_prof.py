@@ -19,7 +19,7 @@ os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
 
 KERNEL = "mmp_level_kernel"
-summary = {"kernel": KERNEL, "command": "rocprofv3 --pmc <group> -- python3 bench.py --no-cpu-baseline --no-mfma-leg --steps 10 --warmup 2",
+summary = {"kernel": KERNEL, "command": "rocprofv3 --pmc <group> -- python3 bench.py --no-cpu-baseline --no-fp32-leg --steps 10 --warmup 2",
            "counters_avg_per_launch": {}, "by_grid": {}}
 for group in ("pmc_fetch", "pmc_write", "pmc_sq"):
     path = os.path.join(src, group, "bench_counter_collection.csv")

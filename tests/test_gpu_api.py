@@ -14,12 +14,12 @@ from conftest import load_json
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["tables", "mfma"])
+@pytest.fixture(scope="module", params=["fp16_filter", "fp32_only"])
 def dic(request):
-    """every API test runs twice: deeper levels from the cross-correlation table (default) / by GEMM"""
+    """every API test runs twice: fp16 matrix-core filter + float64 re-score (default) / fp32 correlations only"""
     import csc_amd
     d = csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.005), np.arange(0.010, 0.036, 0.002), [1])
-    d.device_bank().use_gram = request.param == "tables"
+    d.device_bank().fp32_only = request.param == "fp32_only"
     return d
 
 
@@ -249,16 +249,16 @@ def test_config2_depth_truncation_and_determinism(dic, config2):
         assert np.array_equal(omp.node_atom[:, d - 1], res.node_atom[:, res.node_id(d, 0)])
 
 
-def test_config2_table_path_equals_mfma_path(dic, config2):
+def test_config2_fp16_filter_equals_fp32_path(dic, config2):
     """the two correlation paths select the same atoms on all 3200 signals; MSE to 1e-12"""
     sigs, _, res = config2
     bank = dic.device_bank()
-    old = bank.use_gram
+    old = bank.fp32_only
     try:
-        bank.use_gram = not old
+        bank.fp32_only = not old
         other = bank.mmpdf_batch(sigs, 5, 3, 3, 0.8, want_coef=True)
     finally:
-        bank.use_gram = old
+        bank.fp32_only = old
     assert other.stats[0] == 0
     assert np.array_equal(other.node_pos, res.node_pos) and np.array_equal(other.node_atom, res.node_atom)
     assert np.allclose(other.node_mse, res.node_mse, rtol=1e-12, atol=0)

@@ -15,38 +15,14 @@ from conftest import GOLDEN, load_json
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["tables", "mfma"])
+@pytest.fixture(scope="module", params=["fp16_filter", "fp32_only"])
 def bank(request, golden_bank):
-    """both ways of getting a deeper node's correlations: from the cross-correlation table (default) and
-    by a GEMM on the node's residual"""
+    """both ways of getting a node's correlations: the fp16 matrix-core filter in front of the float64 re-score
+    (default) and fp32 correlations only"""
     from csc_amd.engine import DeviceBank
     b = DeviceBank(golden_bank["bank"])
-    b.use_gram = request.param == "tables"
+    b.fp32_only = request.param == "fp32_only"
     return b
-
-
-def test_gram_table(bank, golden_bank):
-    if not bank.use_gram:
-        pytest.skip("table path only")
-    b = golden_bank["bank"]
-    K, L = b.shape
-    P = 738 - L + 1
-    raw = bank.gram_table(738).cpu().numpy()
-    assert raw.size == K * 144 * 512
-    # two fp16 copies, the second shifted by one element
-    h = raw[:K * 144 * 512].view(np.float16).reshape(2, K, 144, 512)
-    assert np.array_equal(h[1][:, :, 1:], h[0][:, :, :-1]) and not h[1][:, :, 0].any()
-    g = h[0].astype(np.float64)
-    perm = bank.bank32t.cpu().numpy()[16 * 9 * 512:].view(np.int32)[:144]
-    assert not g[:, perm < 0].any() and not g[:, :, 2 * P - 1:].any()
-    rng = np.random.default_rng(0)
-    for _ in range(200):
-        ks, c, dp = rng.integers(K), rng.integers(1, 144), rng.integers(-(P - 1), P)
-        k = perm[c]
-        lo, hi = max(0, -dp), min(L, L - dp)
-        want = np.float16(np.float32(np.dot(b[k, lo:hi], b[ks, lo + dp:hi + dp])))
-        assert abs(g[ks, c, dp + P - 1] - float(want)) <= 2.0 ** -11 * abs(float(want)) + 2.0 ** -24, (ks, c, dp)
-    assert bank.lib.csc_gram_elems(K, L, L + 256) == 0          # P = 257: no table, the GEMM path is used
 
 
 def test_bank_pack(bank, golden_bank):
