@@ -743,7 +743,7 @@ __device__ __forceinline__ void node_of_block(int Fd, size_t& s, int& j) {
 // ---- pieces of a node's work shared by the register-resident and the tiled level kernels ------------
 
 // residual -> LDS (fp64 + fp32 window copy), ancestors' (pos, atom), parent's coefficients and Cholesky
-// factor.  Returns the fp32 candidate band delta = 2^-14 * ||residual||.  Ends with a barrier.
+// factor.  Returns the fp32 candidate band delta = 2^-14 * ||residual|| * max_k ||a_k||.  Ends with a barrier.
 __device__ __forceinline__ float node_prologue(const LevelArgs& a, NodeLds* sl, double* r64, float* r32,
                                                int Npad, int R32, const double* __restrict__ rin, size_t s, int j,
                                                double& rnorm2_out, double (&first)[4]) {
@@ -779,7 +779,7 @@ __device__ __forceinline__ float node_prologue(const LevelArgs& a, NodeLds* sl, 
     __syncthreads();
     const double rnorm2 = sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3];
     rnorm2_out = rnorm2;
-    return DELTA_REL * (float)sqrt(rnorm2);
+    return DELTA_REL * (float)sqrt(rnorm2) * sqrtf(*a.amax2);          // fp32 product: error ~ ||a|| ||r||
 }
 
 // (c) fp64 re-score of the candidates in sl->cand_idx (one wave per candidate), (d) the choice: fp64

@@ -141,3 +141,80 @@ def test_mmpdf_deep_trees(bank, golden_signals):
     for s, ref in enumerate(deep["c4_K7_B64_thr0.8"]):
         assert len(ref["nodes"]) == 340
         _compare_tree(res, s, ref, 4, 7)
+
+
+# ---- the fp16 filter at its edges: scales outside its range, bands too crowded to settle ------------------
+def _oracle_nodes_match(res, od, sigs, K, c, B, thr, rel=1e-9):
+    from oracle import csc_oracle as O
+    for s, sig in enumerate(sigs):
+        t = O.OracleTree(od, sig, K, c, thr, "direct")
+        t.run(B)
+        for path, (pos, atom, mse) in t.all_nodes().items():
+            digits = [int(x) for x in path.split("-")]
+            nid = res.node_id(len(digits), sum((o - 1) * c ** i for i, o in enumerate(digits)))
+            assert (int(res.node_pos[s, nid]), int(res.node_atom[s, nid])) == (pos, atom), (s, path)
+            assert abs(res.node_mse[s, nid] - mse) <= rel * mse + 1e-300, (s, path)
+
+
+@pytest.mark.parametrize("scale", [1e-4, 30.0, 300.0])
+def test_scaled_dictionary_vs_oracle(golden_bank, golden_signals, oracle_dict, scale):
+    """atom norms 1e-4 / 30 / 300: the filter's error bound scales with max ||a_k|| (30), and outside
+    [1e-3, 1e2] the nodes go straight to the fp32 product; selections equal the oracle's on the scaled bank"""
+    import copy
+    from csc_amd.engine import DeviceBank
+    od = copy.copy(oracle_dict)
+    od.bank = oracle_dict.bank * scale
+    bank = DeviceBank(od.bank)
+    sigs = golden_signals["signals"][5::16]
+    res = bank.mmpdf_batch(sigs, 4, 3, 3, 0.8)
+    assert res.stats[0] == 0
+    _oracle_nodes_match(res, od, sigs, 4, 3, 3, 0.8)
+
+
+@pytest.mark.parametrize("amp", [1e-17, 1e16])
+def test_extreme_signal_amplitudes_vs_oracle(bank, golden_signals, oracle_dict, amp):
+    """||r||^2 outside [1e-30, 1e30]: no fp16 scaling is attempted, the fp32 product decides"""
+    sigs = golden_signals["signals"][2::16] * amp
+    res = bank.mmpdf_batch(sigs, 3, 2, 2, 0.8)
+    _oracle_nodes_match(res, oracle_dict, sigs, 3, 2, 2, 0.8)
+
+
+def test_crowded_band_falls_back_to_fp32(golden_bank, golden_signals, oracle_dict):
+    """143 near-copies of one atom (relative differences 1e-3): every atom sits inside the fp16 band of the best
+    one, more than the filter's candidate list holds, so the nodes are multiplied again in fp32 (stats[3]) and
+    still select what the oracle selects"""
+    import copy
+    from csc_amd.engine import DeviceBank
+    rng = np.random.default_rng(5)
+    base = oracle_dict.bank[70]
+    od = copy.copy(oracle_dict)
+    od.bank = base[None, :] * (1.0 + 1e-3 * rng.standard_normal((143, 1))) + 1e-4 * rng.standard_normal((143, base.size)) * (base != 0)
+    sigs = golden_signals["signals"][1::16]
+    for fp32_only in (False, True):
+        bank = DeviceBank(od.bank)
+        bank.fp32_only = fp32_only
+        res = bank.mmpdf_batch(sigs, 2, 1, 1, 1.0)
+        assert res.stats[0] == 0
+        assert (res.stats[3] > 0) == (not fp32_only)
+        _oracle_nodes_match(res, od, sigs, 2, 1, 1, 1.0)
+
+
+def test_noiseless_signals_both_paths(bank, golden_bank, oracle_dict):
+    """exact 3-atom signals: the first three levels equal the oracle's; below that the residual is rounding noise
+    (its arg-max is not a property of the algorithm), but the two correlation paths must still agree bit for bit
+    because both decide on the same float64 re-score"""
+    from csc_amd.engine import DeviceBank
+    rng = np.random.default_rng(3)
+    b = golden_bank["bank"]
+    sigs = np.zeros((6, 738))
+    for s in range(6):
+        for p, k, c in zip(rng.choice(247, 3, replace=False), rng.choice(143, 3, replace=False), (1.0, 0.7, 0.4)):
+            sigs[s, p:p + b.shape[1]] += c * b[k]
+    res = bank.mmpdf_batch(sigs, 5, 1, 1, 1.0)
+    other = DeviceBank(b)
+    other.fp32_only = not bank.fp32_only
+    res2 = other.mmpdf_batch(sigs, 5, 1, 1, 1.0)
+    assert np.array_equal(res.node_pos, res2.node_pos) and np.array_equal(res.node_atom, res2.node_atom)
+    assert np.array_equal(res.node_mse, res2.node_mse)
+    _oracle_nodes_match(type("R", (), {"node_id": res.node_id, "node_pos": res.node_pos[:, :3], "node_atom": res.node_atom[:, :3],
+                                       "node_mse": res.node_mse[:, :3]})(), oracle_dict, sigs, 3, 1, 1, 1.0, rel=1e-6)
