@@ -88,6 +88,7 @@ struct LevelArgs {
     int32_t* stats;
     const _Float16* bank16;  // the bank in fp16, blocked like bank32t with (k-group, column, 8 rows) fragments
     const float* amax2;   // max_k ||a_k||^2 (scales the fp16 error bound)
+    const double* anorm2; // [K] ||a_k||^2
     TreeShape ts;
 };
 
@@ -169,6 +170,28 @@ __device__ __forceinline__ double dot_range(const double* __restrict__ a, PB b, 
         for (int u = 0; u < 8; ++u) acc = fma(av[u], bv[u], acc);
     }
     return acc;
+}
+
+// two such sums at once over a full wave (both sets of loads in flight together)
+template <typename PB>
+__device__ __forceinline__ void dot_pair(const double* __restrict__ a0, PB b0, const double* __restrict__ a1, PB b1,
+                                         int n, int lane, double& s0, double& s1) {
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int base = 0; base < n; base += 64 * 8) {
+        double av0[8], bv0[8], av1[8], bv1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + lane + 64 * u;
+            const bool ok = i < n;
+            av0[u] = ok ? a0[i] : 0.0;
+            av1[u] = ok ? a1[i] : 0.0;
+            bv0[u] = ok ? b0[i] : 0.0;
+            bv1[u] = ok ? b1[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc0 = fma(av0[u], bv0[u], acc0); acc1 = fma(av1[u], bv1[u], acc1); }
+    }
+    s0 = acc0; s1 = acc1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -360,6 +383,36 @@ __device__ __forceinline__ void slab_mfma16(const _Float16* rs, const _Float16* 
     }
 }
 
+// the first RING16 - 1 slabs; issued at the very start of the node, under the prologue
+__device__ __forceinline__ void gemm16_prefetch(const _Float16* __restrict__ tile, int nslab, _Float16* ring) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int q = 0; q < RING16 - 1; ++q)
+        if (q < nslab) stage_slab16(tile + (size_t)q * SLABF, ring + q * SLABF, wave, lane);
+}
+
+// one slab: wait for its copy, barrier, issue the copy three slabs ahead, multiply column tiles NI0 .. 8
+template <int NI0>
+__device__ __forceinline__ void slab_step16(const _Float16* __restrict__ tile, int nslab, int s, const _Float16* ra,
+                                            _Float16* ring, int wave, int lane, f32x4 (&acc)[MT][NT]) {
+    // slab s has landed (this wave's copies), then everybody's: the barrier also says that every wave is done
+    // reading slab s - 1, whose ring slot the copy issued below overwrites
+    const int later = min(RING16 - 2, nslab - 1 - s);                // slabs issued after s and still allowed in flight
+    if (wave == 0) { if (later == 2) WAIT_VM(6); else if (later == 1) WAIT_VM(3); else WAIT_VM(0); }
+    else           { if (later == 2) WAIT_VM(4); else if (later == 1) WAIT_VM(2); else WAIT_VM(0); }
+    __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));   // lgkmcnt(0): own LDS reads done
+    __builtin_amdgcn_s_barrier();
+    if (s + RING16 - 1 < nslab)
+        stage_slab16(tile + (size_t)(s + RING16 - 1) * SLABF, ring + ((s + RING16 - 1) % RING16) * SLABF, wave, lane);
+    slab_mfma16<NI0>(ra + 32 * s, ring + (s % RING16) * SLABF + lane * 8, acc);
+}
+
+// gemm16_prefetch must have been issued (and no other vector-memory traffic may be in flight).
+// Zero-padding skip: bank columns are sorted by support, so in slab s only column tiles >= ctz(masks[s]) hold
+// non-zeros, and with centred supports that bound is high at both ends of the atom and 0 in the middle.  The slab
+// range is cut into five runs -- tiles 6..8 only / 3..8 / all / 3..8 / 6..8 -- each a loop of straight-line code
+// (choosing the variant inside one loop body costs the register allocator ~150 spills).
 __device__ __forceinline__ void corr_tile_gemm16(const _Float16* __restrict__ tile, const uint32_t* masks, int nslab,
                                                  const _Float16* r16, _Float16* ring, f32x4 (&acc)[MT][NT]) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -372,29 +425,25 @@ __device__ __forceinline__ void corr_tile_gemm16(const _Float16* __restrict__ ti
     // fragment (mi, slab s) of this lane: elements 64 wave + 16 mi + lr + 8 lq + 32 s ... + 7 of the window
     const _Float16* ra = r16 + (lr & 7) * R16_CS + 64 * wave + (lr & 8) + 8 * lq;
 
-#pragma unroll
-    for (int q = 0; q < RING16 - 1; ++q)
-        if (q < nslab) stage_slab16(tile + (size_t)q * SLABF, ring + q * SLABF, wave, lane);
-    for (int s = 0; s < nslab; ++s) {
-        // slab s has landed (this wave's copies), then everybody's: the barrier also says that every wave is done
-        // reading slab s - 1, whose ring slot the copy issued below overwrites
-        const int later = min(RING16 - 2, nslab - 1 - s);            // slabs issued after s and still allowed in flight
-        if (wave == 0) { if (later == 2) WAIT_VM(6); else if (later == 1) WAIT_VM(3); else WAIT_VM(0); }
-        else           { if (later == 2) WAIT_VM(4); else if (later == 1) WAIT_VM(2); else WAIT_VM(0); }
-        __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));   // lgkmcnt(0): own LDS reads done
-        __builtin_amdgcn_s_barrier();
-        if (s + RING16 - 1 < nslab)
-            stage_slab16(tile + (size_t)(s + RING16 - 1) * SLABF, ring + ((s + RING16 - 1) % RING16) * SLABF, wave, lane);
+    // first tile that holds a non-zero, per slab (9 = none); runs from both ends
+    int p6 = 0, p3, q3, q6 = nslab;
+    auto first_tile = [&](int s) {
         const uint32_t m = __builtin_amdgcn_readfirstlane(masks[s]);
-        if (m) {
-            // column tiles below ctz(m) hold only zero padding in this slab; skipped in steps of three tiles so
-            // that each variant is straight-line code (all fragment reads in flight before the first MFMA)
-            const int ni0 = __builtin_ctz(m);
-            const _Float16* sb = ring + (s % RING16) * SLABF + lane * 8;
-            const _Float16* rs = ra + 32 * s;
-            (void)ni0; slab_mfma16<0>(rs, sb, acc);
-        }
-    }
+        return m ? (int)__builtin_ctz(m) : NT;
+    };
+    while (p6 < nslab && first_tile(p6) >= 6) ++p6;
+    p3 = p6;
+    while (p3 < nslab && first_tile(p3) >= 3) ++p3;
+    while (q6 > p3 && first_tile(q6 - 1) >= 6) --q6;
+    q3 = q6;
+    while (q3 > p3 && first_tile(q3 - 1) >= 3) --q3;
+
+    int s = 0;
+    for (; s < p6; ++s) slab_step16<6>(tile, nslab, s, ra, ring, wave, lane, acc);
+    for (; s < p3; ++s) slab_step16<3>(tile, nslab, s, ra, ring, wave, lane, acc);
+    for (; s < q3; ++s) slab_step16<0>(tile, nslab, s, ra, ring, wave, lane, acc);
+    for (; s < q6; ++s) slab_step16<3>(tile, nslab, s, ra, ring, wave, lane, acc);
+    for (; s < nslab; ++s) slab_step16<6>(tile, nslab, s, ra, ring, wave, lane, acc);
     __syncthreads();
 }
 
@@ -459,14 +508,17 @@ __global__ void bank_pack16_kernel(const double* __restrict__ bank64, int K, int
     out[i] = (k >= 0 && l < L) ? (_Float16)(float)bank64[(size_t)k * L + l] : (_Float16)0.f;
 }
 
-// amax2 = max_k ||a_k||^2 (one wave per atom)
+// anorm2[k] = ||a_k||^2, amax2 = their maximum (one wave per atom)
 __global__ __launch_bounds__(64) void bank_norm_kernel(const double* __restrict__ bank64, int K, int L,
-                                                       float* __restrict__ amax2) {
+                                                       float* __restrict__ amax2, double* __restrict__ anorm2) {
     const int k = blockIdx.x, lane = threadIdx.x;
     double v = 0.0;
     for (int l = lane; l < L; l += 64) { const double x = bank64[(size_t)k * L + l]; v = fma(x, x, v); }
     v = wave_sum(v);
-    if (lane == 63) atomicMax(reinterpret_cast<unsigned*>(amax2), __float_as_uint((float)v * 1.0000002f));   // >= 0, rounded up
+    if (lane == 63) {
+        anorm2[k] = v;
+        atomicMax(reinterpret_cast<unsigned*>(amax2), __float_as_uint((float)v * 1.0000002f));   // >= 0, rounded up
+    }
 }
 
 // masks[tile][slab]: bit ni set <=> the block holds a non-zero value
@@ -717,7 +769,8 @@ struct NodeLds {
     int perm[CSC_TILE_COLS];       // atom of each bank column (-1 = padding)
     float wmax[WG / 64];
     int widx[WG / 64], wsupp[WG / 64];
-    int cand_cnt, chosen, i32, bad, odd_slot;
+    int cand_cnt, chosen, i32, bad, beta_ok;      // beta_ok: `beta` = <a_chosen, r> from the re-score
+    double beta;
     float m32;
     PROF_FIELDS
 };
@@ -790,16 +843,22 @@ __device__ __forceinline__ void rescore_and_choose(const LevelArgs& a, NodeLds* 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, L = a.L, d = a.depth;
     const int ncand = min(ncand_raw, CAND_CAP);
-    for (int c = wave; c < ncand; c += WG / 64) {
-        const int idx = sl->cand_idx[c];
-        const int p = idx / K, k = idx - p * K;
-        double v = dot_range<64>(a.bank64 + (size_t)k * L, r64 + p, 0, L, lane);
-        v = wave_sum(v);
-        if (lane == 63) sl->cand_val[c] = v;
+    for (int c = 2 * wave; c < ncand; c += 2 * (WG / 64)) {          // two candidates per wave and round trip
+        const int i0 = sl->cand_idx[c], i1 = sl->cand_idx[min(c + 1, ncand - 1)];
+        const int p0 = i0 / K, k0 = i0 - p0 * K, p1 = i1 / K, k1 = i1 - p1 * K;
+        double v0, v1;
+        dot_pair(a.bank64 + (size_t)k0 * L, r64 + p0, a.bank64 + (size_t)k1 * L, r64 + p1, L, lane, v0, v1);
+        v0 = wave_sum(v0);
+        v1 = wave_sum(v1);
+        if (lane == 63) {
+            sl->cand_val[c] = v0;
+            if (c + 1 < ncand) sl->cand_val[c + 1] = v1;
+        }
     }
     __syncthreads();
     if (tid == 0) {
         int chosen;
+        sl->beta_ok = 0;
         if (ncand_raw > CAND_CAP) {
             chosen = min(min(sl->widx[0], sl->widx[1]), min(sl->widx[2], sl->widx[3]));
             if (a.stats) atomicAdd(&a.stats[0], 1);
@@ -812,13 +871,14 @@ __device__ __forceinline__ void rescore_and_choose(const LevelArgs& a, NodeLds* 
             if (zero_band) {
                 int z = 0x7fffffff;
                 for (int w = 0; w < WG / 64; ++w) z = min(z, sl->wsupp[w]);
-                if (z != 0x7fffffff && (0.0 > bestv || (0.0 == bestv && z < besti))) besti = z;
+                if (z != 0x7fffffff && (0.0 > bestv || (0.0 == bestv && z < besti))) { besti = z; bestv = NAN; }
             }
             chosen = besti;
+            if (ncand && bestv == bestv) { sl->beta = bestv; sl->beta_ok = 1; }   // <a_chosen, r>, reused by the solve
         }
         if (a.stats) atomicAdd(&a.stats[2], ncand);
         // all-NaN correlations (NaN / Inf in the signal): np.argmax of an all-NaN array is 0 (src/csc/mmp.py:227)
-        if ((unsigned)chosen >= (unsigned)(a.P * K)) chosen = 0;
+        if ((unsigned)chosen >= (unsigned)(a.P * K)) { chosen = 0; sl->beta_ok = 0; }
         sl->chosen = chosen;
         sl->sup_pos[d] = chosen / K;
         sl->sup_atom[d] = chosen - (chosen / K) * K;
@@ -881,23 +941,27 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
         }
         return;
     }
-    // ---- one new Gram column (fp64 dots, one per half-wave) ------------------------------------------
+    // ---- one new Gram column: <a_new, a_q> for the d ancestors (fp64 dots, one per wave); ||a_new||^2 comes from
+    // the bank's table and <a_new, r_parent> from the re-score that chose the atom (recomputed here when the choice
+    // was not a re-scored candidate) -----------------------------------------------------------------------------
     {
-        const int hw = tid >> 5, hl = tid & 31;
         const double* an = a.bank64 + (size_t)k_sel * L;
-        for (int q = hw; q < d + 2; q += WG / 32) {
+        const int nd = d + (sl->beta_ok ? 0 : 1);
+        for (int q = wave; q < nd; q += WG / 64) {
             double v;
-            if (q < d) {                                         // <a_new @ p_sel, a_q @ p_q>
+            if (q < d) {                                             // <a_new @ p_sel, a_q @ p_q>
                 const double* aq = a.bank64 + (size_t)sl->sup_atom[q] * L;
-                const int dp = p_sel - sl->sup_pos[q];           // a_q index = i + dp
-                v = dot_range<32>(an, aq + dp, max(0, -dp), min(L, L - dp), hl);
-            } else if (q == d) {                                 // ||a_new||^2
-                v = dot_range<32>(an, an, 0, L, hl);
-            } else {                                             // <a_new, r_parent>
-                v = dot_range<32>(an, r64 + p_sel, 0, L, hl);
+                const int dp = p_sel - sl->sup_pos[q];               // a_q index = i + dp
+                v = dot_range<64>(an, aq + dp, max(0, -dp), min(L, L - dp), lane);
+            } else {                                                 // <a_new, r_parent>
+                v = dot_range<64>(an, r64 + p_sel, 0, L, lane);
             }
-            v = half_wave_sum(v);
-            if (hl == 31) sl->g[q] = v;
+            v = wave_sum(v);
+            if (lane == 63) sl->g[q < d ? q : d + 1] = v;
+        }
+        if (tid == 0) {
+            sl->g[d] = a.anorm2[k_sel];
+            if (sl->beta_ok) sl->g[d + 1] = sl->beta;
         }
     }
     __syncthreads();
@@ -947,19 +1011,24 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
             const int n = n0 + tid + WG * u;
             v[u] = n < N ? r64[n] : 0.0;
         }
-#pragma unroll 2
-        for (int i = 0; i <= d; ++i) {
-            const double* ai = a.bank64 + (size_t)sl->sup_atom[i] * L;
-            const int pi = sl->sup_pos[i];
-            const double xi = sl->x[i];
-            double av[3];
+        for (int i0 = 0; i0 <= d; i0 += 4) {                          // four atoms' loads in flight together
+            double av[4][3], xi[4];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int o = n0 + tid + WG * u - pi;
-                av[u] = ((unsigned)o < (unsigned)L) ? ai[o] : 0.0;
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = min(i0 + ii, d);
+                const double* ai = a.bank64 + (size_t)sl->sup_atom[i] * L;
+                const int pi = sl->sup_pos[i];
+                xi[ii] = (i0 + ii <= d) ? sl->x[i] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int o = n0 + tid + WG * u - pi;
+                    av[ii][u] = ((unsigned)o < (unsigned)L && i0 + ii <= d) ? ai[o] : 0.0;
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 3; ++u) v[u] = fma(-xi, av[u], v[u]);
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int u = 0; u < 3; ++u) v[u] = fma(-xi[ii], av[ii][u], v[u]);
         }
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
@@ -1206,6 +1275,8 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
 
     PROF_INIT(0);
+    // the first bank slabs of the fp16 product start their way L2 -> LDS now, under the prologue
+    if (a.bank16) gemm16_prefetch(a.bank16, (L + SLAB - 1) / SLAB, reinterpret_cast<_Float16*>(slab));
     const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
     double rnorm2, first[4];
     const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2, first);
@@ -1587,13 +1658,16 @@ static int ceil8(int v) { return (v + 7) & ~7; }
 static int n_tiles(int K) { return (K + CSC_TILE_COLS - 1) / CSC_TILE_COLS; }
 static int n_slabs(int L) { return (L + SLAB - 1) / SLAB; }
 static size_t tile_floats(int K, int L) { return (size_t)n_tiles(K) * n_slabs(L) * SLABF; }
-// packed bank buffer: [fp32 tiles][meta per tile][fp16 tiles][amax2 + spare (16 floats)]
+// packed bank buffer: [fp32 tiles][meta per tile][fp16 tiles][amax2 + spare (16 floats)][anorm2: K doubles]
 static size_t bank16_offset(int K, int L) { return tile_floats(K, L) + (size_t)n_tiles(K) * META_INTS; }
 static const _Float16* bank_tiles16(const float* d_bank32t, int K, int L) {
     return reinterpret_cast<const _Float16*>(d_bank32t + bank16_offset(K, L));
 }
 static const float* bank_amax2(const float* d_bank32t, int K, int L) {
     return d_bank32t + bank16_offset(K, L) + tile_floats(K, L) / 2;
+}
+static const double* bank_anorm2(const float* d_bank32t, int K, int L) {
+    return reinterpret_cast<const double*>(bank_amax2(d_bank32t, K, L) + 16);
 }
 static const int32_t* bank_meta(const float* d_bank32t, int K, int L) {
     return reinterpret_cast<const int32_t*>(d_bank32t + tile_floats(K, L));
@@ -1654,7 +1728,7 @@ const char* csc_last_error(void) { return g_err; }
 
 size_t csc_bank32_elems(int K, int L) {
     if (K <= 0 || L <= 0) return 0;
-    return bank16_offset(K, L) + tile_floats(K, L) / 2 + 16;
+    return bank16_offset(K, L) + tile_floats(K, L) / 2 + 16 + 2 * (size_t)K;
 }
 
 int csc_sim_words(int N, int L) {
@@ -1681,7 +1755,8 @@ int csc_bank_pack(const double* d_bank64, int K, int L, float* d_bank32t, void* 
                        nslab, meta, const_cast<_Float16*>(bank_tiles16(d_bank32t, K, L)), total);
     float* amax2 = const_cast<float*>(bank_amax2(d_bank32t, K, L));
     if (hipMemsetAsync(amax2, 0, 16 * sizeof(float), st) != hipSuccess) FAIL(-1, "csc_bank_pack: hipMemsetAsync failed");
-    hipLaunchKernelGGL(bank_norm_kernel, dim3(K), dim3(64), 0, st, d_bank64, K, L, amax2);
+    hipLaunchKernelGGL(bank_norm_kernel, dim3(K), dim3(64), 0, st, d_bank64, K, L, amax2,
+                       const_cast<double*>(bank_anorm2(d_bank32t, K, L)));
     return launch_status("bank_pack kernels");
 }
 
@@ -1783,6 +1858,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         a.NS = N + TRI(max_sparsity) + max_sparsity; a.mode = mode;
         a.bank16 = (!tiled && !(flags & CSC_FLAG_FP32_ONLY)) ? bank_tiles16(d_bank32t, K, L) : nullptr;
         a.amax2 = bank_amax2(d_bank32t, K, L);
+        a.anorm2 = bank_anorm2(d_bank32t, K, L);
         a.resid_in = (d == 0) ? d_signals : ws[d & 1];
         a.resid_out = (d + 1 < max_sparsity) ? ws[(d + 1) & 1] : nullptr;
         a.node_pos = d_node_pos; a.node_atom = d_node_atom; a.node_mse = d_node_mse; a.node_coef = d_node_coef;

@@ -51,9 +51,9 @@ def test_sizes_helpers():
     from csc_amd import _lib
     lib = _lib.lib()
     # per 144-atom tile: 16 slabs x 9 column blocks x (32 x 16) floats + 208 ints of metadata + the same blocks in fp16;
-    # then max_k ||a_k||^2 (+ spare)
-    assert lib.csc_bank32_elems(143, 492) == 512 * 144 + 208 + 256 * 144 + 16
-    assert lib.csc_bank32_elems(145, 492) == 2 * (512 * 144 + 208 + 256 * 144) + 16
+    # then max_k ||a_k||^2 (+ spare) and ||a_k||^2 as doubles
+    assert lib.csc_bank32_elems(143, 492) == 512 * 144 + 208 + 256 * 144 + 16 + 2 * 143
+    assert lib.csc_bank32_elems(145, 492) == 2 * (512 * 144 + 208 + 256 * 144) + 16 + 2 * 145
     assert lib.csc_sim_words(738, 492) == 2 * ((2 * 247 - 1 + 63) // 64)
     assert lib.csc_sim_words(100, 492) == 0
     # per frontier node: N residual samples + the packed Cholesky factor (15 doubles at depth 5)
