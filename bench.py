@@ -220,18 +220,33 @@ def main():
         # K atoms at all P shifts, 2*P*K*L flops, n_sel = 13 nodes per signal over the 5 level launches
         flops_per_launch = S * flops_per_signal / MAX_SPARSITY
         achieved = flops_per_launch / (launch_ms * 1e-3) / 1e12
-        # MFMA flops actually issued by the fp16 filter: every (32-row x 16-atom) bank block, 4 waves x 4
-        # v_mfma_f32_16x16x32_f16 (16384 flop each) per node
+        # MFMA flops actually issued by the fp16 filter: per slab the column tiles from 6, 3 or 0 on (the kernel's five
+        # runs over the support-sorted bank, corr_tile_gemm16), 4 waves x 4 v_mfma_f32_16x16x32_f16 (16384 flop) per
+        # (slab, tile) and node
         nslab = (L + 31) // 32
-        issued16 = S * n_sel * nslab * 9 * 4 * 4 * 16384.0 / MAX_SPARSITY / (launch_ms * 1e-3) / 1e12
+        off = nslab * 9 * 512
+        meta = bank.bank32t[off:off + 208].view(torch.int32).cpu().numpy()
+        first = [(int(m) & -int(m)).bit_length() - 1 if m else 9 for m in meta[144:144 + nslab]]
+        p6 = 0
+        while p6 < nslab and first[p6] >= 6:
+            p6 += 1
+        p3 = p6
+        while p3 < nslab and first[p3] >= 3:
+            p3 += 1
+        q6 = nslab
+        while q6 > p3 and first[q6 - 1] >= 6:
+            q6 -= 1
+        q3 = q6
+        while q3 > p3 and first[q3 - 1] >= 3:
+            q3 -= 1
+        blocks16 = 3 * p6 + 6 * (p3 - p6) + 9 * (q3 - p3) + 6 * (q6 - q3) + 3 * (nslab - q6)
+        issued16 = S * n_sel * blocks16 * 4 * 4 * 16384.0 / MAX_SPARSITY / (launch_ms * 1e-3) / 1e12
         fp32_path = None
         if spans_m:
             launch_ms_m = float(np.mean([ms for _, ms in spans_m]))
             achieved_m = flops_per_launch / (launch_ms_m * 1e-3) / 1e12
             # fp32 MFMA flops issued: blocks holding only the atoms' zero padding are skipped, every other
             # block costs 4 waves x 32 v_mfma_f32_16x16x4_f32 (2048 flop each) per node
-            off = nslab * 9 * 512
-            meta = bank.bank32t[off:off + 208].view(torch.int32).cpu().numpy()
             blocks = sum(9 - (int(m) & -int(m)).bit_length() + 1 for m in meta[144:144 + nslab] if m)
             issued = S * n_sel * blocks * 4 * 32 * 2048.0 / MAX_SPARSITY / (launch_ms_m * 1e-3) / 1e12
             fp32_path = {
@@ -273,8 +288,9 @@ def main():
                          "launches_timed": len(spans),
                          "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "mfma_issued": {"tflops": issued16, "frac_of_peak": issued16 / FP16_MFMA_PEAK_TFLOPS,
-                                         "note": "v_mfma_f32_16x16x32_f16 flops issued by the filter (padding "
-                                                 "blocks included)"},
+                                         "blocks_per_node": blocks16, "of_dense_blocks": nslab * 9,
+                                         "note": "v_mfma_f32_16x16x32_f16 flops issued by the filter; runs of "
+                                                 "all-padding column tiles are skipped"},
                          "note": "correlations on the fp16 matrix cores as a filter (arithmetic dtype f16, fp32 "
                                  "accumulation), selection decided by a float64 re-score of the entries in the "
                                  "fp16 rounding band; `achieved` counts the reference's dense 2*P*K*L flops per "
