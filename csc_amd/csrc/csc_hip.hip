@@ -89,6 +89,7 @@ struct LevelArgs {
     const _Float16* bank16;  // the bank in fp16, blocked like bank32t with (k-group, column, 8 rows) fragments
     const float* amax2;   // max_k ||a_k||^2 (scales the fp16 error bound)
     const double* anorm2; // [K] ||a_k||^2
+    uint8_t* flags;       // [S][F[d]] lean kernel -> mmp_level_kernel: 1 = this node still has to be done (in fp32)
     TreeShape ts;
 };
 
@@ -1270,6 +1271,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     size_t s;
     int j;
     node_of_block(Fd, s, j);
+    if (a.flags && !a.flags[s * Fd + j]) return;                      // settled by the lean kernel
     const int nch = children_of(a, j);
     if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
     if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
@@ -1310,6 +1312,256 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     PROF_MARK(1);
     select_children<true>(a, sl, r64, simrow, s, j, nch, delta, acc);
     __syncthreads();
+    PROF_MARK(9);
+}
+
+// ---- the lean level kernel: the same node, three column groups at a time ----------------------------------
+// mmp_level_kernel keeps the whole (256 x 144) correlation matrix in registers, 144 VGPRs per lane, which allows
+// two nodes per CU -- and a node is a chain of short dependent steps, so the CU idles.  A node does not need the
+// matrix at once: only its maximum and the few entries within the band of it.  Here the fp16 product is taken in
+// three groups of NG = 3 column tiles (48 atoms, 48 accumulator VGPRs, 3 KB of bank per slab): sweep 1 keeps each
+// group's maximum (after suppression by the earlier siblings, read from the similarity table), sweep 2 collects
+// the candidates from the groups that reach the band, recomputing them -- 4/3 of the MFMA work, a third of the
+// registers, LDS for four nodes per CU.  Everything behind the candidates is the shared code.
+// A node the fp16 filter cannot settle is flagged (a.flags) and left to mmp_level_kernel in fp32, launched behind.
+#define NG 3
+#define GBLK (NG * BLKF)               // halves of one group-slab in the ring
+
+// group-slab s of group g: blocks 3g .. 3g + 2 of slab s, one 1 KiB copy per wave 0..2
+__device__ __forceinline__ void stage_group16(const _Float16* gslab, _Float16* lslab, int g, int wave, int lane) {
+    if (wave < NG)
+        __builtin_amdgcn_global_load_lds((gptr_t)(gslab + (NG * g + wave) * BLKF + lane * 8),
+                                         (lptr_t)(lslab + wave * BLKF), 16, 0, 0);
+}
+
+// acc[mi][nj] = correlations of positions 64 wave + 16 mi + ..., column tile 3 g + nj, over slabs [s0, s1)
+__device__ __forceinline__ void gemm16_group(const _Float16* __restrict__ tile, int g, int s0, int s1,
+                                             const _Float16* r16, _Float16* ring, f32x4 (&acc)[MT][NG]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NG; ++nj) acc[mi][nj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const _Float16* ra = r16 + (lr & 7) * R16_CS + 64 * wave + (lr & 8) + 8 * lq;
+    WAIT_VM(0);                                                      // nothing of ours in flight: the counts below hold
+#pragma unroll
+    for (int q = 0; q < RING16 - 1; ++q)
+        if (s0 + q < s1) stage_group16(tile + (size_t)(s0 + q) * SLABF, ring + q * GBLK, g, wave, lane);
+    for (int s = s0; s < s1; ++s) {
+        const int later = min(RING16 - 2, s1 - 1 - s);               // one copy per slab and wave (waves 0..2)
+        if (later == 2) WAIT_VM(2); else if (later == 1) WAIT_VM(1); else WAIT_VM(0);
+        __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));   // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        if (s + RING16 - 1 < s1)
+            stage_group16(tile + (size_t)(s + RING16 - 1) * SLABF, ring + ((s - s0 + RING16 - 1) % RING16) * GBLK, g, wave, lane);
+        const _Float16* sb = ring + ((s - s0) % RING16) * GBLK + lane * 8;
+        f16x8 af[MT], bf[NG];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) af[mi] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 16 * mi);
+#pragma unroll
+        for (int nj = 0; nj < NG; ++nj) bf[nj] = *reinterpret_cast<const f16x8*>(sb + nj * BLKF);
+#pragma unroll
+        for (int nj = 0; nj < NG; ++nj)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+                acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
+    }
+    __syncthreads();
+}
+
+// masking of the entries outside the matrix + suppression by the first t siblings (bits from the similarity
+// table in L2); returns the lane's maximum over its unsuppressed entries, lane_supp = it holds a suppressed one
+__device__ __forceinline__ float group_finish(const LevelArgs& a, const NodeLds* sl, const int* sib_pos,
+                                              const int* sib_atom, int g, int t, int (&permv)[NG],
+                                              f32x4 (&acc)[MT][NG], bool& lane_supp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int K = a.K, P = a.P, W = a.W;
+    const int prow = 64 * wave + 4 * lq;
+#pragma unroll
+    for (int nj = 0; nj < NG; ++nj) permv[nj] = sl->perm[16 * (NG * g + nj) + lr];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+        if (64 * wave + 16 * mi + 15 >= P) {                         // wave-uniform
+#pragma unroll
+            for (int nj = 0; nj < NG; ++nj)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    if (prow + 16 * mi + rg >= P) acc[mi][nj][rg] = -INFINITY;
+        }
+#pragma unroll
+    for (int nj = 0; nj < NG; ++nj)
+        if (permv[nj] < 0) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) acc[mi][nj] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+    lane_supp = false;
+    for (int q = 0; q < t; ++q) {
+        const int dpb = prow - sib_pos[q] + P - 1;                   // bit index of (mi, rg) = (0, 0); >= 0
+        const int w0 = dpb >> 5, b0 = dpb & 31;
+        const uint32_t* srow = a.sim_bits + (size_t)sib_atom[q] * K * W;
+#pragma unroll
+        for (int nj = 0; nj < NG; ++nj) {
+            const uint32_t* row = srow + (size_t)max(permv[nj], 0) * W;
+            const uint32_t wd0 = row[min(w0, W - 1)], wd1 = row[min(w0 + 1, W - 1)], wd2 = row[min(w0 + 2, W - 1)];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int off = b0 + 16 * mi + rg;               // < 32 + 52
+                    const uint32_t wd = off < 32 ? wd0 : (off < 64 ? wd1 : wd2);
+                    const bool hit = ((wd >> (off & 31)) & 1u) && acc[mi][nj][rg] > -INFINITY;
+                    acc[mi][nj][rg] = hit ? __uint_as_float(SUPP_BITS) : acc[mi][nj][rg];
+                    lane_supp |= hit;
+                }
+        }
+    }
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NG; ++nj)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) lmax = fmaxf(lmax, acc[mi][nj][rg]);
+    return lmax;
+}
+
+struct LeanLds {
+    float gmax[NT / NG];
+    int sib_pos[CSC_MAX_CONNECTIONS], sib_atom[CSC_MAX_CONNECTIONS];
+    int s0[NT / NG], s1[NT / NG];      // slab range of each group (outside it the group's blocks are zero padding)
+};
+
+__global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a) {
+    extern __shared__ double lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int N = a.N, K = a.K, L = a.L, d = a.depth;
+    const int nslab = (L + SLAB - 1) / SLAB;
+
+    // ---- LDS carve-up: ring [RING16][GBLK] halves | r64 [Npad] | r16 [R16_COPIES][R16_CS] | NodeLds | LeanLds
+    const int Npad = (N + 3) & ~3;
+    _Float16* ring = reinterpret_cast<_Float16*>(lds_raw);
+    double* r64 = lds_raw + (RING16 * GBLK) / 4;
+    _Float16* r16 = reinterpret_cast<_Float16*>(r64 + Npad);
+    NodeLds* sl = reinterpret_cast<NodeLds*>(r16 + R16_COPIES * R16_CS);
+    LeanLds* ll = reinterpret_cast<LeanLds*>(sl + 1);
+
+    const int Fd = a.ts.F[d];
+    size_t s;
+    int j;
+    node_of_block(Fd, s, j);
+    const int nch = children_of(a, j);
+    const int stride = a.ts.pw[d];
+    if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
+    if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
+
+    PROF_INIT(0);
+    const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
+    double rnorm2, first[4];
+    node_prologue(a, sl, r64, nullptr, Npad, 0, rin, s, j, rnorm2, first);
+    PROF_MARK(0);
+    const float am2 = *a.amax2, am = sqrtf(am2);
+    const bool ok = am2 > 1e-6f && am2 < 1e4f && rnorm2 > 1e-30 && rnorm2 < 1e30;
+    if (tid == 0) a.flags[s * Fd + j] = ok ? 0 : 1;
+    if (!ok) return;                                                 // NaN / Inf / extreme scales: fp32 launch
+    const float band = 2.f * ((9.765625e-04f + DELTA_REL + 1e-6f) * am + 2.9802322e-08f * sqrtf((float)L) * (1.f + am));
+    build_r16(r64, N, (float)(1.0 / sqrt(rnorm2)), first, r16);
+    if (tid < NT / NG) {
+        // group g's blocks hold a non-zero only in slabs whose first non-zero tile is below 3 (g + 1)
+        int lo = nslab, hi = 0;
+        for (int q = 0; q < nslab; ++q) {
+            const uint32_t m = sl->masks[q];
+            if (m && (int)__builtin_ctz(m) < NG * (tid + 1)) { lo = min(lo, q); hi = q + 1; }
+        }
+        ll->s0[tid] = min(lo, hi);
+        ll->s1[tid] = hi;
+    }
+    __syncthreads();
+
+    f32x4 acc[MT][NG];
+    int permv[NG];
+    const int prow = 64 * wave + 4 * lq;
+    for (int t = 0; t < nch; ++t) {
+        // ---- sweep 1: group maxima -----------------------------------------------------------------------
+        for (int g = 0; g < NT / NG; ++g) {
+            bool lane_supp;
+            gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
+            const float lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, t, permv, acc, lane_supp);
+            const float bv = wave_max(lane_supp ? fmaxf(lmax, 0.f) : lmax);
+            if (lane == 63) sl->wmax[wave] = bv;
+            __syncthreads();
+            if (tid == 0) ll->gmax[g] = fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
+            __syncthreads();
+        }
+        PROF_MARK(1);
+        const float m32 = fmaxf(fmaxf(ll->gmax[0], ll->gmax[1]), ll->gmax[2]);
+        const float tau = m32 - band;
+        if (tid == 0) sl->cand_cnt = 0;
+        __syncthreads();
+        if (0.f >= tau && t > 0) {                 // the value 0 of suppressed entries may compete: fp32 launch
+            if (tid == 0) { a.flags[s * Fd + j] = 1; if (a.stats) atomicAdd(&a.stats[3], 1); }
+            return;
+        }
+        // ---- sweep 2: candidates from the groups that reach the band; the last group is still in registers --
+        for (int g = NT / NG - 1; g >= 0; --g) {
+            if (!(ll->gmax[g] >= tau)) continue;                      // uniform
+            bool lane_supp;
+            float lmax;
+            if (g != NT / NG - 1) {
+                gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
+                lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, t, permv, acc, lane_supp);
+            } else {
+                lmax = -INFINITY;
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < NG; ++nj)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) lmax = fmaxf(lmax, acc[mi][nj][rg]);
+            }
+            if (lmax >= tau) {
+                uint32_t mk[2] = {0u, 0u};
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                        for (int nj = 0; nj < NG; ++nj) {
+                            const int e = (4 * mi + rg) * NG + nj;
+                            mk[e >> 5] |= (acc[mi][nj][rg] >= tau) ? (1u << (e & 31)) : 0u;
+                        }
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    uint32_t mm = mk[w];
+                    while (mm) {
+                        const int e = 32 * w + __builtin_ctz(mm);
+                        mm &= mm - 1;
+                        const int r = e / NG, nj = e - r * NG;
+                        const int idx = (prow + 16 * (r >> 2) + (r & 3)) * K + sl->perm[16 * (NG * g + nj) + lr];
+                        const int slot = atomicAdd(&sl->cand_cnt, 1);
+                        if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        PROF_MARK(3);
+        const int ncand_raw = sl->cand_cnt;
+        if (ncand_raw > CAND_CAP) {                // too many entries in the fp16 band: fp32 launch
+            if (tid == 0) { a.flags[s * Fd + j] = 1; if (a.stats) atomicAdd(&a.stats[3], 1); }
+            return;
+        }
+        rescore_and_choose(a, sl, r64, ncand_raw, false);
+        PROF_MARK(5);
+        const int jc = j + t * stride;
+        const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
+        if (tid == 0) { ll->sib_pos[t] = sl->sup_pos[d]; ll->sib_atom[t] = sl->sup_atom[d]; }
+        child_solve_and_write(a, sl, r64, s, jc, cid);
+        __syncthreads();
+    }
     PROF_MARK(9);
 }
 
@@ -1799,16 +2051,25 @@ int csc_tree_nodes(int max_sparsity, int connections, int branches, int* level_s
     return nn;
 }
 
-static size_t node_ws_bytes(int S, int N, int max_sparsity, const TreeShape& ts) {
+static int frontier_max(int max_sparsity, const TreeShape& ts) {
     int fmax = 1;
     for (int d = 1; d < max_sparsity; ++d) fmax = ts.F[d] > fmax ? ts.F[d] : fmax;
-    return 2 * (size_t)S * fmax * (N + TRI(max_sparsity) + max_sparsity) * sizeof(double);
+    return fmax;
+}
+static size_t node_ws_bytes(int S, int N, int max_sparsity, const TreeShape& ts) {
+    return 2 * (size_t)S * frontier_max(max_sparsity, ts) * (N + TRI(max_sparsity) + max_sparsity) * sizeof(double);
+}
+static size_t flag_ws_bytes(int S, int max_sparsity, const TreeShape& ts) {      // one byte per frontier node
+    return ((size_t)S * frontier_max(max_sparsity, ts) + 15) & ~(size_t)15;
+}
+static size_t lean_lds_bytes(int N) {
+    return (size_t)RING16 * GBLK * 2 + (size_t)ceil4(N) * 8 + R16_COPIES * R16_CS * 2 + sizeof(NodeLds) + sizeof(LeanLds);
 }
 
 size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections, int branches) {
     TreeShape ts;
     if (make_shape(max_sparsity, connections, branches, &ts) < 0 || S <= 0 || N <= 0) return 0;
-    return node_ws_bytes(S, N, max_sparsity, ts);
+    return node_ws_bytes(S, N, max_sparsity, ts) + flag_ws_bytes(S, max_sparsity, ts);
 }
 
 static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
@@ -1835,7 +2096,12 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
     if (n_slabs(L) > MAX_SLABS) FAIL(-8, "atom length %d exceeds %d", L, MAX_SLABS * SLAB);
     if (max_sparsity > P * K) FAIL(-2, "max_sparsity exceeds the number of activations");
     const size_t node_bytes = node_ws_bytes(S, N, max_sparsity, ts);
-    const size_t need = node_bytes;
+    const size_t need = node_bytes + flag_ws_bytes(S, max_sparsity, ts);
+    uint8_t* node_flags = max_sparsity > 1 ? reinterpret_cast<uint8_t*>(static_cast<char*>(d_workspace) + node_bytes) : nullptr;
+    // the lean kernel (fp16 filter, four nodes per CU) takes the level first; needs the flag buffer (max_sparsity = 1
+    // passes no workspace), the canonical window length and a tree level that fits the flag buffer
+    const bool lean = !tiled && !(flags & CSC_FLAG_FP32_ONLY) && node_flags && N <= 4 * WG && n_slabs(L) * SLAB <= 512 &&
+                      !getenv("CSC_NO_LEAN");
     if (max_sparsity > 1 && (workspace_bytes < need || !d_workspace))
         FAIL(-10, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
     const int Lp = n_slabs(L) * SLAB;                      // residual window zero-padded to whole slabs
@@ -1866,8 +2132,19 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         const size_t grid = (size_t)S * ts.F[d];
         if (grid > 0x7fffffffULL) FAIL(-11, "batch too large for one launch (%zu workgroups)", grid);
         const int span = timer_begin(st, d);
-        if (tiled) hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
-        else hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
+        a.flags = nullptr;
+        if (tiled) {
+            hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
+        } else if (lean && (connections == 1 || ts.pw[d] >= ts.F[d + 1])) {
+            // every node of this level has one child (node j's second child j + pw[d] falls outside F[d + 1]); with
+            // siblings the lean kernel would repeat its sweeps per sibling and the register-resident kernel wins
+            a.flags = node_flags;
+            hipLaunchKernelGGL(mmp_level_lean_kernel, dim3((unsigned)grid), dim3(WG), lean_lds_bytes(N), st, a);
+            a.bank16 = nullptr;                                      // what it flagged: fp32
+            hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
+        } else {
+            hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
+        }
         timer_end(st, span);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) FAIL((int)e, "mmp_level_kernel launch failed at level %d: %s", d, hipGetErrorString(e));

@@ -58,7 +58,8 @@ def test_sizes_helpers():
     assert lib.csc_sim_words(100, 492) == 0
     # per frontier node: N residual samples + the packed Cholesky factor (15 doubles at depth 5)
     # + max_sparsity coefficients, two generations
-    assert lib.csc_mmpdf_workspace_bytes(10, 738, 5, 3, 3) == 2 * 10 * 3 * (738 + 15 + 5) * 8
+    # (+ one flag byte per frontier node, rounded up to 16)
+    assert lib.csc_mmpdf_workspace_bytes(10, 738, 5, 3, 3) == 2 * 10 * 3 * (738 + 15 + 5) * 8 + 32
 
 
 def test_candidate_paths_match_reference_table():
