@@ -2101,7 +2101,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
     // the lean kernel (fp16 filter, four nodes per CU) takes the level first; needs the flag buffer (max_sparsity = 1
     // passes no workspace), the canonical window length and a tree level that fits the flag buffer
     const bool lean = !tiled && !(flags & CSC_FLAG_FP32_ONLY) && node_flags && N <= 4 * WG && n_slabs(L) * SLAB <= 512 &&
-                      !getenv("CSC_NO_LEAN");
+                      !(flags & CSC_FLAG_NO_LEAN);
     if (max_sparsity > 1 && (workspace_bytes < need || !d_workspace))
         FAIL(-10, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
     const int Lp = n_slabs(L) * SLAB;                      // residual window zero-padded to whole slabs

@@ -131,6 +131,9 @@ class DeviceBank:
         # correlations on the fp16 matrix cores as a filter in front of the float64 re-score (same results);
         # set to True to correlate in fp32 only (CSC_FLAG_FP32_ONLY)
         self.fp32_only = False
+        # single-child tree levels on the column-group ("lean") kernel, four nodes per CU (same results);
+        # set to False to keep them on the register-resident kernel (CSC_FLAG_NO_LEAN)
+        self.lean = True
 
     def similarity_table(self, N: int, threshold: float):
         key = (int(N), float(threshold))
@@ -269,7 +272,7 @@ class DeviceBank:
                 }
             rc = self.lib.csc_mmpdf_batch(
                 _ptr(self.bank32t), _ptr(self.bank64), _ptr(sim), self.K, self.L, _ptr(sig), S, N,
-                max_sparsity, connections, branches, 1 if self.fp32_only else 0, _ptr(out["ws"]), out["ws"].numel() * 8,
+                max_sparsity, connections, branches, (1 if self.fp32_only else 0) | (0 if self.lean else 2), _ptr(out["ws"]), out["ws"].numel() * 8,
                 _ptr(out["node_pos"]), _ptr(out["node_atom"]), _ptr(out["node_mse"]), _ptr(out["node_coef"]),
                 _ptr(out["rec_mse"]), _ptr(out["rec_leaf"]), _ptr(out["rec_sel"]), _ptr(out["stats"]),
                 _stream(dev))

@@ -32,6 +32,7 @@ extern "C" {
 #define CSC_MAX_SPARSITY 16    /* largest tree depth / support size                           */
 #define CSC_MAX_CONNECTIONS 8  /* largest number of siblings per node                         */
 #define CSC_FLAG_FP32_ONLY 1   /* csc_mmpdf_batch flags: skip the fp16 matrix-core filter      */
+#define CSC_FLAG_NO_LEAN 2     /* keep single-child levels on the register-resident kernel      */
 
 int csc_abi_version(void);
 const char* csc_last_error(void);
@@ -81,7 +82,10 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
  *   flags       0, or CSC_FLAG_FP32_ONLY: correlate in fp32 only (v_mfma_f32_16x16x4_f32).  By default a
  *               node's correlations are first taken on the fp16 matrix cores as a filter and every entry
  *               within the fp16 rounding bound of the maximum is re-scored in float64; the selections are
- *               the float64 arg-max either way (identical results, the flag exists to check that)
+ *               the float64 arg-max either way (identical results, the flag exists to check that).
+ *               CSC_FLAG_NO_LEAN: tree levels on which every node has one child normally run on a kernel
+ *               that takes the fp16 product in three column groups (four nodes per CU instead of two);
+ *               the flag keeps them on the register-resident kernel (identical results, same purpose)
  *   d_signals   [S][N] f64
  *   d_node_pos  [S][NN] int32   selected position of the node      (src/csc/mmp.py:74-76)
  *   d_node_atom [S][NN] int32   selected atom index
@@ -98,6 +102,8 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
  *               to the fp32 arg-max (candidate overflow), [1] re-selected activations (dead Cholesky
  *               columns), [2] number of fp64 re-scored candidates, [3] nodes the fp16 filter could not
  *               settle (multiplied again in fp32)
+ *   workspace   csc_mmpdf_workspace_bytes(...) bytes: two generations of node residuals + one flag byte per
+ *               frontier node
  */
 int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
                     int K, int L, const double* d_signals, int S, int N,

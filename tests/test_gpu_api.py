@@ -14,12 +14,14 @@ from conftest import load_json
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["fp16_filter", "fp32_only"])
+@pytest.fixture(scope="module", params=["fp16_filter", "fp32_only", "no_lean"])
 def dic(request):
-    """every API test runs twice: fp16 matrix-core filter + float64 re-score (default) / fp32 correlations only"""
+    """every API test runs three times: fp16 matrix-core filter + float64 re-score (default: single-child levels on
+    the column-group kernel) / fp32 correlations only / the fp16 filter on the register-resident kernel at every level"""
     import csc_amd
     d = csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.005), np.arange(0.010, 0.036, 0.002), [1])
     d.device_bank().fp32_only = request.param == "fp32_only"
+    d.device_bank().lean = request.param != "no_lean"
     return d
 
 

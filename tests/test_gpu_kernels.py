@@ -15,13 +15,14 @@ from conftest import GOLDEN, load_json
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["fp16_filter", "fp32_only"])
+@pytest.fixture(scope="module", params=["fp16_filter", "fp32_only", "no_lean"])
 def bank(request, golden_bank):
     """both ways of getting a node's correlations: the fp16 matrix-core filter in front of the float64 re-score
     (default) and fp32 correlations only"""
     from csc_amd.engine import DeviceBank
     b = DeviceBank(golden_bank["bank"])
     b.fp32_only = request.param == "fp32_only"
+    b.lean = request.param != "no_lean"
     return b
 
 
