@@ -14,7 +14,8 @@ already resident in HBM; with N > 1 every rank holds its own 3200 signals (weak 
 step ends with the ONE gather of the fixed-size sparVar records on rank 0 over RCCL.
 
 Reported next to `value`:
-  roofline      matrix-core roofline of the dominant kernel (mmp_level_kernel), launch durations measured
+  roofline      matrix-core roofline of the level kernels (mmp_level_lean_kernel on the single-child levels 1-4,
+                mmp_level_kernel on level 0; one timed span per tree level), launch durations measured
                 live with HIP events on the launch stream (csc_timer in include/csc_hip.h).  A node's
                 correlations are taken on the fp16 matrix cores as a filter and the entries in its rounding
                 band are re-scored in float64: algorithmic flops per signal = n_sel * 2*P*K*L, n_sel = 13
@@ -283,14 +284,15 @@ def main():
                                                               if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP16_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "mmp_level_kernel", "launch_ms_avg": launch_ms, "launch_ms_by_level": per_level,
+                         "kernel": "mmp_level_lean_kernel (levels 1-4) + mmp_level_kernel (level 0)", "launch_ms_avg": launch_ms, "launch_ms_by_level": per_level,
                          "flops_per_launch": flops_per_launch, "flops_per_signal": flops_per_signal,
                          "launches_timed": len(spans),
                          "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "mfma_issued": {"tflops": issued16, "frac_of_peak": issued16 / FP16_MFMA_PEAK_TFLOPS,
                                          "blocks_per_node": blocks16, "of_dense_blocks": nslab * 9,
-                                         "note": "v_mfma_f32_16x16x32_f16 flops issued by the filter; runs of "
-                                                 "all-padding column tiles are skipped"},
+                                         "note": "v_mfma_f32_16x16x32_f16 flops issued by the filter when no column "
+                                                 "group is multiplied twice (lower bound; runs of all-padding "
+                                                 "column tiles are skipped)"},
                          "note": "correlations on the fp16 matrix cores as a filter (arithmetic dtype f16, fp32 "
                                  "accumulation), selection decided by a float64 re-score of the entries in the "
                                  "fp16 rounding band; `achieved` counts the reference's dense 2*P*K*L flops per "

@@ -2135,9 +2135,10 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         a.flags = nullptr;
         if (tiled) {
             hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
-        } else if (lean && (connections == 1 || ts.pw[d] >= ts.F[d + 1])) {
+        } else if (lean && grid > 512 && (connections == 1 || ts.pw[d] >= ts.F[d + 1])) {
             // every node of this level has one child (node j's second child j + pw[d] falls outside F[d + 1]); with
-            // siblings the lean kernel would repeat its sweeps per sibling and the register-resident kernel wins
+            // siblings the lean kernel would repeat its sweeps per sibling and the register-resident kernel wins;
+            // 512 nodes or fewer are all resident at once on either kernel
             a.flags = node_flags;
             hipLaunchKernelGGL(mmp_level_lean_kernel, dim3((unsigned)grid), dim3(WG), lean_lds_bytes(N), st, a);
             a.bank16 = nullptr;                                      // what it flagged: fp32

@@ -18,40 +18,53 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
 
-KERNEL = "mmp_level_kernel"
-summary = {"kernel": KERNEL, "command": "rocprofv3 --pmc <group> -- python3 bench.py --no-cpu-baseline --no-fp32-leg --steps 10 --warmup 2",
-           "counters_avg_per_launch": {}, "by_grid": {}}
+KERNELS = ("mmp_level_lean_kernel", "mmp_level_kernel")     # levels 1-4 (+ their fp32 follow-up launch) / level 0
+summary = {"kernels": KERNELS,
+           "command": "rocprofv3 --pmc <group> -- python3 bench.py --no-cpu-baseline --no-fp32-leg --steps 10 --warmup 2",
+           "per_kernel": {}}
+totals = defaultdict(float)
+n_lean = 0
 for group in ("pmc_fetch", "pmc_write", "pmc_sq"):
     path = os.path.join(src, group, "bench_counter_collection.csv")
     if not os.path.exists(path):
         continue
-    acc, by_grid = defaultdict(list), defaultdict(lambda: defaultdict(list))
+    acc = {k: defaultdict(list) for k in KERNELS}
     info = {}
     for row in csv.DictReader(open(path)):
-        if not row["Kernel_Name"].startswith(KERNEL):
+        name = row["Kernel_Name"]
+        k = next((k for k in KERNELS if name.startswith(k)), None)
+        if k is None:
             continue
-        acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
-        by_grid[row["Grid_Size"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-        info = {k: row[k] for k in ("Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
-                                    "Accum_VGPR_Count", "SGPR_Count")}
-    for name, vals in acc.items():
-        summary["counters_avg_per_launch"][name] = sum(vals) / len(vals)
-        summary.setdefault("launches", {})[name] = len(vals)
-    for g, d in by_grid.items():
+        # the fp32 follow-up launches of mmp_level_kernel behind the lean kernel find nothing to do: counted in
+        # the traffic total, kept out of the level-0 averages (they run the full grid of the level, 9600 nodes)
+        key = k if not (k == "mmp_level_kernel" and int(row["Grid_Size"]) > 3200 * 256) else "mmp_level_kernel (follow-up)"
+        acc.setdefault(key, defaultdict(list))[row["Counter_Name"]].append(float(row["Counter_Value"]))
+        if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            totals[row["Counter_Name"]] += float(row["Counter_Value"])
+        if k == "mmp_level_lean_kernel" and row["Counter_Name"] == "FETCH_SIZE":
+            n_lean += 1
+        info[key] = {f: row[f] for f in ("Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
+                                         "Accum_VGPR_Count", "SGPR_Count", "Grid_Size")}
+    for key, d in acc.items():
         for name, vals in d.items():
-            summary["by_grid"].setdefault(g, {})[name] = sum(vals) / len(vals)
-    summary["resources"] = info
-c = summary["counters_avg_per_launch"]
-if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-    fetch = c["FETCH_SIZE"] * 1024 * 2          # KiB -> B, gfx950 x2 correction
-    write = c["WRITE_SIZE"] * 1024
-    summary["hbm"] = {"fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write,
-                      "bytes_per_launch": fetch + write}
+            e = summary["per_kernel"].setdefault(key, {"counters_avg_per_launch": {}, "launches": {}})
+            e["counters_avg_per_launch"][name] = sum(vals) / len(vals)
+            e["launches"][name] = len(vals)
+            e["resources"] = info.get(key, {})
+if n_lean and "FETCH_SIZE" in totals and "WRITE_SIZE" in totals:
+    levels = n_lean // 4 * 5                     # level launches timed by bench.py: 4 lean levels + level 0 per step
+    fetch = totals["FETCH_SIZE"] * 1024 * 2 / levels          # KiB -> B, gfx950 x2 correction
+    write = totals["WRITE_SIZE"] * 1024 / levels
+    summary["hbm"] = {"fetch_bytes_per_level_corrected": fetch, "write_bytes_per_level": write,
+                      "bytes_per_level": fetch + write, "levels": levels}
     json.dump({"bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "profile": tag,
-               "note": "avg over the 5 level launches of one csc_mmpdf_batch (3200 signals); FETCH_SIZE KiB x1024 x2 "
-                       "(gfx950 correction), WRITE_SIZE KiB x1024; separate --pmc passes"},
+               "note": "avg over the 5 tree levels of one csc_mmpdf_batch (3200 signals), all level kernels of a level "
+                       "together; FETCH_SIZE KiB x1024 x2 (gfx950 correction), WRITE_SIZE KiB x1024; separate --pmc passes"},
               open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
-if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
-    summary["mfma_busy_over_sq_busy"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CYCLES"]
+for key, e in summary["per_kernel"].items():
+    c = e["counters_avg_per_launch"]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
+        # MFMA-busy cycles are summed over the 1024 SIMDs, SQ_BUSY_CYCLES over the 32 shader engines' sequencers
+        e["mfma_busy_fraction_of_simd_cycles"] = (c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (c["SQ_BUSY_CYCLES"] / 32)
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
