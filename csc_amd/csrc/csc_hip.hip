@@ -475,7 +475,7 @@ __global__ void bank_rank_kernel(const int32_t* __restrict__ keys, int K, int np
     }
     const int col = npad + rank;
     meta[(col / CSC_TILE_COLS) * META_INTS + col % CSC_TILE_COLS] = k;
-    if (k < npad) meta[k] = -1;                                       // pads sit in tile 0
+    for (int q = k; q < npad; q += K) meta[q] = -1;                   // pads sit in tile 0 (there can be more of them than atoms)
 }
 
 __global__ void bank_pack_kernel(const double* __restrict__ bank64, int K, int L, int nslab,

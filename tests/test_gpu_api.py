@@ -367,3 +367,49 @@ def test_odd_shapes_vs_oracle():
                     undecided.append(path)
                     continue
                 assert abs(res.node_mse[s, nid] - mse) <= 1e-9 * mse + 1e-30
+
+
+def test_random_shapes_all_variants_agree():
+    """random dictionaries (6-120 atoms, atom lengths not multiples of 32), signal lengths (1-256 positions) and tree
+    shapes: the lean fp16 kernel, the register-resident fp16 kernel and the fp32-only path give the same trees, and
+    a sample of them equals the oracle's"""
+    import csc_amd
+    from oracle import csc_oracle as O
+    rng = np.random.default_rng(2024)
+    b_all, y_all = np.arange(0.005, 0.06, 0.005), np.arange(0.010, 0.036, 0.002)
+    for trial in range(8):
+        b = sorted(rng.choice(b_all, rng.integers(2, 9), replace=False).tolist())
+        y = sorted(rng.choice(y_all, rng.integers(3, 14), replace=False).tolist())
+        d = csc_amd.ZSDictionary.from_values(b, y, [1])
+        od = O.OracleDictionary(b, y, [1])
+        K, L = od.bank.shape
+        P = int(rng.integers(1, 257))
+        N = L + P - 1
+        c, Kx = int(rng.integers(1, 4)), int(rng.integers(2, 6))
+        B = int(rng.integers(1, 7))
+        S = 600                                   # more than 512 nodes per level: the lean kernel is in play
+        sigs = 0.05 * rng.standard_normal((S, N))
+        for s in range(S):
+            for _ in range(int(rng.integers(1, 4))):
+                p = int(rng.integers(0, P))
+                sigs[s, p:p + L] += rng.uniform(0.3, 1.0) * od.bank[int(rng.integers(K))]
+        Kx = min(Kx, P * K)
+        bank = d.device_bank()
+        out = {}
+        for name, fp32_only, lean in (("lean", False, True), ("resident", False, False), ("fp32", True, True)):
+            bank.fp32_only, bank.lean = fp32_only, lean
+            out[name] = bank.mmpdf_batch(sigs, Kx, c, B, 0.8, want_coef=True)
+            assert out[name].stats[0] == 0, (trial, name)
+        for name in ("resident", "fp32"):
+            assert np.array_equal(out[name].node_pos, out["lean"].node_pos), (trial, name, K, L, P, c, Kx, B)
+            assert np.array_equal(out[name].node_atom, out["lean"].node_atom), (trial, name)
+            assert np.allclose(out[name].node_mse, out["lean"].node_mse, rtol=1e-12, atol=0)
+        res = out["lean"]
+        for s in range(0, S, 150):
+            t = O.OracleTree(od, sigs[s], Kx, c, 0.8, "direct")
+            t.run(B)
+            for path, (pos, atom, mse) in t.all_nodes().items():
+                digits = [int(x) for x in path.split("-")]
+                nid = res.node_id(len(digits), sum((o - 1) * c ** i for i, o in enumerate(digits)))
+                assert (int(res.node_pos[s, nid]), int(res.node_atom[s, nid])) == (pos, atom), (trial, s, path)
+                assert abs(res.node_mse[s, nid] - mse) <= 1e-9 * mse + 1e-30
