@@ -413,3 +413,38 @@ def test_random_shapes_all_variants_agree():
                 nid = res.node_id(len(digits), sum((o - 1) * c ** i for i, o in enumerate(digits)))
                 assert (int(res.node_pos[s, nid]), int(res.node_atom[s, nid])) == (pos, atom), (trial, s, path)
                 assert abs(res.node_mse[s, nid] - mse) <= 1e-9 * mse + 1e-30
+
+
+def test_random_shapes_matching_pursuit_vs_oracle():
+    """plain matching pursuit on random dictionaries / signal lengths, 600 signals per call (the lean kernel takes
+    the single-child levels): the selected activation and the MSE of every iteration against the oracle"""
+    import csc_amd
+    from oracle import csc_oracle as O
+    rng = np.random.default_rng(77)
+    b_all, y_all = np.arange(0.005, 0.06, 0.005), np.arange(0.010, 0.036, 0.002)
+    for trial in range(4):
+        b = sorted(rng.choice(b_all, rng.integers(2, 9), replace=False).tolist())
+        y = sorted(rng.choice(y_all, rng.integers(3, 14), replace=False).tolist())
+        d = csc_amd.ZSDictionary.from_values(b, y, [1])
+        od = O.OracleDictionary(b, y, [1])
+        K, L = od.bank.shape
+        P = int(rng.integers(2, 257))
+        N = L + P - 1
+        iters = int(rng.integers(2, 6))
+        S = 600
+        sigs = 0.05 * rng.standard_normal((S, N))
+        for s in range(S):
+            for _ in range(int(rng.integers(1, 4))):
+                p = int(rng.integers(0, P))
+                sigs[s, p:p + L] += rng.uniform(0.3, 1.0) * od.bank[int(rng.integers(K))]
+        pos, atom, mse, mask = d.device_bank().mp_batch(sigs, iters)
+        for s in range(0, S, 120):
+            prev = {}
+            for i, (m, approx) in enumerate(O.mp_steps(od, sigs[s], iters, "direct")):
+                changed = [k for k, v in m.items() if prev.get(k) != v]
+                assert len(changed) == 1
+                p_ref, k_ref = divmod(changed[0], K)
+                assert (int(pos[s, i]), int(atom[s, i])) == (p_ref, k_ref), (trial, s, i)
+                want = float(np.mean((sigs[s] - approx) ** 2))
+                assert abs(mse[s, i] - want) <= 1e-9 * want, (trial, s, i)
+                prev = m

@@ -94,3 +94,32 @@ def test_multi_unit_tree_vs_oracle():
         sup = res1.branch(s, 3, 0)
         _, coef = od.project(sigs[s], sup, N, "direct")
         assert np.allclose(res1.node_coef[s, res1.node_id(3, 0), :3], coef, rtol=1e-9)
+
+
+def test_random_tiled_shapes_vs_oracle():
+    """random dictionaries / signal lengths beyond one register tile (more than 144 atoms and/or more than 256
+    positions, remainder row blocks of every size): every node of a few signals against the CPU oracle"""
+    import csc_amd
+    from oracle import csc_oracle as O
+    rng = np.random.default_rng(99)
+    for trial in range(5):
+        nb, ny = int(rng.integers(6, 20)), int(rng.integers(6, 20))
+        b = np.linspace(0.005, 0.058, nb).tolist()
+        y = np.linspace(0.010, 0.035, ny).tolist()
+        d = csc_amd.ZSDictionary.from_values(b, y, [1])
+        od = O.OracleDictionary(b, y, [1])
+        K, L = od.bank.shape
+        P = int(rng.integers(257, 700)) if (K <= 144 or rng.random() < 0.6) else int(rng.integers(20, 257))
+        N = L + P - 1
+        c, Kx, B = int(rng.integers(1, 4)), int(rng.integers(2, 5)), int(rng.integers(1, 6))
+        sigs = 0.03 * rng.standard_normal((5, N))
+        for s in range(5):
+            for _ in range(3):
+                p = int(rng.integers(0, P))
+                sigs[s, p:p + L] += rng.uniform(0.4, 1.2) * od.bank[int(rng.integers(K))]
+        res, _ = d._batch(sigs, Kx, c, B, 0.75, want_coef=True)
+        assert res.stats[0] == 0
+        for s in range(5):
+            t = O.OracleTree(od, sigs[s], Kx, c, 0.75, "direct")
+            t.run(B)
+            _check_nodes(res, s, {k: v for k, v in t.all_nodes().items()}, c)
