@@ -219,3 +219,58 @@ def test_noiseless_signals_both_paths(bank, golden_bank, oracle_dict):
     assert np.array_equal(res.node_mse, res2.node_mse)
     _oracle_nodes_match(type("R", (), {"node_id": res.node_id, "node_pos": res.node_pos[:, :3], "node_atom": res.node_atom[:, :3],
                                        "node_mse": res.node_mse[:, :3]})(), oracle_dict, sigs, 3, 1, 1, 1.0, rel=1e-6)
+
+
+def test_random_shapes_correlate_project_match_vs_oracle():
+    """the stand-alone entry points on random dictionaries (fewer atoms than padding columns included) and signal
+    lengths: csc_correlate, csc_project_batch, csc_match_batch against the oracle"""
+    from csc_amd.engine import DeviceBank
+    from helpers import OracleBank
+    from oracle import csc_oracle as O
+    rng = np.random.default_rng(314)
+    b_all, y_all = np.arange(0.005, 0.06, 0.005), np.arange(0.010, 0.036, 0.002)
+    for trial in range(5):
+        b = sorted(rng.choice(b_all, rng.integers(1, 9), replace=False).tolist())
+        y = sorted(rng.choice(y_all, rng.integers(2, 14), replace=False).tolist())
+        od = O.OracleDictionary(b, y, [1])
+        K, L = od.bank.shape
+        P = int(rng.integers(1, 400))
+        N = L + P - 1
+        bank, ob = DeviceBank(od.bank), OracleBank(od)
+        sigs = rng.standard_normal((7, N))
+        # correlations
+        got = bank.correlate(sigs).cpu().numpy()
+        for s in range(7):
+            want = od.correlations(sigs[s], "direct")
+            assert got[s].shape == want.shape == (P, K)
+            assert np.abs(got[s] - want).max() <= 3e-6 * np.linalg.norm(sigs[s]) * np.sqrt((od.bank ** 2).sum(1).max())
+        # projections on random supports (some padded, some with a repeated activation)
+        kmax = int(rng.integers(1, 7))
+        M = 12
+        sup = np.full((M, kmax, 2), -1, np.int32)
+        for m in range(M):
+            n = int(rng.integers(1, kmax + 1))
+            sup[m, :n, 0] = rng.integers(0, P, n)
+            sup[m, :n, 1] = rng.integers(0, K, n)
+            if n > 1 and rng.random() < 0.3:
+                sup[m, n - 1] = sup[m, 0]
+        idx = rng.integers(0, 7, M).astype(np.int32)
+        coef, mse, approx, _ = bank.project_batch(sigs, sup, idx, want_approx=True)
+        for m in range(M):
+            s_ = [(int(p), int(k)) for p, k in sup[m] if p >= 0]
+            uniq = list(dict.fromkeys(s_))
+            ap, c = od.project(sigs[idx[m]], uniq, N, "direct")
+            want_mse = float(np.mean((sigs[idx[m]] - ap) ** 2))
+            if np.linalg.cond(np.array([[np.dot(od.place(k1, p1, N), od.place(k2, p2, N)) for (p2, k2) in uniq]
+                                        for (p1, k1) in uniq])) < 1e8:
+                assert abs(mse[m] - want_mse) <= 1e-8 * want_mse, (trial, m)
+                assert np.abs(approx[m] - ap).max() <= 1e-7 * np.abs(ap).max() + 1e-12
+        # matching
+        kt, ka = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        T = np.stack([np.stack([rng.integers(0, P, kt), rng.integers(0, K, kt)], 1) for _ in range(20)]).astype(np.int32)
+        A = T[:, :min(kt, ka)].copy()
+        A = np.concatenate([A, np.stack([np.stack([rng.integers(0, P, ka - A.shape[1]), rng.integers(0, K, ka - A.shape[1])], 1)
+                                         for _ in range(20)]).astype(np.int32)], 1) if ka > A.shape[1] else A
+        A[:, :, 0] = np.clip(A[:, :, 0] + rng.integers(-3, 4, A.shape[:2]), 0, P - 1)
+        got_tp = bank.match_batch(T, A, 2, 0.7)
+        assert np.array_equal(got_tp, ob.match_batch(T, A, 2, 0.7)), trial
