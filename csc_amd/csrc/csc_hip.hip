@@ -54,12 +54,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // Development aid (make prof): per-phase shader-clock totals of the level kernels, summed over workgroups
 // (slots 0-15: GEMM nodes, 16-31: table nodes; scripts/phase_prof.py names them).
 #ifdef CSC_PHASE_PROF
-__device__ unsigned long long g_prof[32];
+#define PROF_BUCKETS 256                // the counters are spread over buckets (block index) to keep the atomics apart
+__device__ unsigned long long g_prof[32][PROF_BUCKETS];
 #define PROF_FIELDS unsigned long long prof_t; int prof_base;
 #define PROF_INIT(base) do { if (threadIdx.x == 0) { sl->prof_base = (base); sl->prof_t = __builtin_readcyclecounter(); } } while (0)
 #define PROF_MARK(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) { \
     unsigned long long n_ = __builtin_readcyclecounter(); \
-    atomicAdd(&g_prof[sl->prof_base + (i)], n_ - sl->prof_t); sl->prof_t = n_; } } while (0)
+    atomicAdd(&g_prof[sl->prof_base + (i)][blockIdx.x % PROF_BUCKETS], n_ - sl->prof_t); sl->prof_t = n_; } } while (0)
 #else
 #define PROF_FIELDS
 #define PROF_INIT(base)
@@ -1486,7 +1487,9 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
     const int prow = 64 * wave + 4 * lq;
     for (int t = 0; t < nch; ++t) {
         // ---- sweep 1: group maxima -----------------------------------------------------------------------
-        for (int g = 0; g < NT / NG; ++g) {
+        // widest atoms first, narrowest last: the last group stays in registers for sweep 2, and the narrow atoms'
+        // group is both the one that most often holds the maximum (2 of 3 nodes on config 2) and the cheapest
+        for (int g = NT / NG - 1; g >= 0; --g) {
             bool lane_supp;
             gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
             const float lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, t, permv, acc, lane_supp);
@@ -1506,11 +1509,11 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
             return;
         }
         // ---- sweep 2: candidates from the groups that reach the band; the last group is still in registers --
-        for (int g = NT / NG - 1; g >= 0; --g) {
+        for (int g = 0; g < NT / NG; ++g) {
             if (!(ll->gmax[g] >= tau)) continue;                      // uniform
             bool lane_supp;
             float lmax;
-            if (g != NT / NG - 1) {
+            if (g != 0) {
                 gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
                 lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, t, permv, acc, lane_supp);
             } else {
@@ -2255,8 +2258,13 @@ int csc_timer_read(csc_timer* t, float* ms, int* tag, int n) {
 #ifdef CSC_PHASE_PROF
 int csc_prof_read(unsigned long long* out32, int reset) {
     hipDeviceSynchronize();
-    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z); }
+    static unsigned long long host[32][PROF_BUCKETS];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof), sizeof host) != hipSuccess) return -1;
+    for (int i = 0; i < 32; ++i) {
+        out32[i] = 0;
+        for (int b = 0; b < PROF_BUCKETS; ++b) out32[i] += host[i][b];
+    }
+    if (reset) { memset(host, 0, sizeof host); hipMemcpyToSymbol(HIP_SYMBOL(g_prof), host, sizeof host); }
     return 0;
 }
 #endif

@@ -10,6 +10,8 @@ sig = bench.make_signals(dic, 0)
 bank = dic.device_bank()
 if "--fp32" in sys.argv:            # fp32 correlations only
     bank.fp32_only = True
+if "--no-lean" in sys.argv:
+    bank.lean = False
 d = torch.from_numpy(sig).cuda()
 out = bank.mmpdf_launch(d, 5, 3, 3, 0.8, want_coef=False)
 L = _lib.lib()
@@ -21,7 +23,8 @@ L.csc_prof_read(buf, 1)
 v = np.array(list(buf), dtype=np.float64)
 names = ["prologue", "gemm", "suppress", "max + candidates", "-", "rescore + choose",
          "gram dots", "solve", "residual + write", "tail"]
-rows = (("nodes (fp16 filter, or fp32 only)", 0, 3200 * 13), ("nodes repeated in fp32 after the filter", 16, 3200 * 13))
+rows = (("all nodes (level 0: register-resident kernel, levels 1-4: lean kernel unless --no-lean)", 0, 3200 * 13),
+        ("nodes repeated in fp32 after the filter", 16, 3200 * 13))
 for title, base, nodes in rows:
     w = v[base:base + 10]
     tot = w.sum()
