@@ -52,7 +52,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define R16_CS 776                     // fragment is one aligned 16-byte LDS read; copy stride = 16 mod 128 bytes
 
 // Development aid (make prof): per-phase shader-clock totals of the level kernels, summed over workgroups
-// (slots 0-15: GEMM nodes, 16-31: table nodes; scripts/phase_prof.py names them).
+// (slots 0-15: mmp_level_kernel / the tiled kernel, 16-31: mmp_level_lean_kernel; scripts/phase_prof.py names them).
 #ifdef CSC_PHASE_PROF
 #define PROF_BUCKETS 256                // the counters are spread over buckets (block index) to keep the atomics apart
 __device__ unsigned long long g_prof[32][PROF_BUCKETS];
@@ -1095,19 +1095,42 @@ __device__ __forceinline__ void suppress_similar(const LevelArgs& a, NodeLds* sl
     const int W = a.W, W1 = a.W + 1, K = a.K, P = a.P;               // LDS rows padded by one word
     const uint32_t* g = a.sim_bits + (size_t)k_sel * K * W;
     __syncthreads();
-    for (int i = tid; i < K * W; i += WG) simrow[(i / W) * W1 + (i % W)] = g[i];
+    PROF_MARK(10);
+    // nine words per lane requested together (the asm keeps them live at one point: next to the 144 accumulators the
+    // compiler would otherwise request one, wait, store, nine L2 round trips in a row)
+    for (int base = 0; base < K * W; base += 9 * WG) {
+        uint32_t v[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int i = base + tid + WG * u;
+            v[u] = i < K * W ? g[i] : 0u;
+        }
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                          "+v"(v[8]));
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int i = base + tid + WG * u;
+            if (i < K * W) simrow[(i / W) * W1 + (i % W)] = v[u];
+        }
+    }
     __syncthreads();
-    const int dp0 = 64 * wave + 4 * (lane >> 4) - p_sel + P - 1;     // + 16*mi + rg: bit index of this entry
+    PROF_MARK(11);
+    // this lane's 16 entries of a column tile are bits dp0 + 16*mi + rg of the column's row, dp0 >= 0: a window of
+    // 52 bits, i.e. three words per column tile (one LDS read per entry cost a full LDS latency each, 144 times)
+    const int dp0 = 64 * wave + 4 * (lane >> 4) - p_sel + P - 1;
+    const int w0 = dp0 >> 5, b0 = dp0 & 31;
     bool any = false;
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
         const uint32_t* row = simrow + max(permv[ni], 0) * W1;
+        const uint32_t wd0 = row[min(w0, W - 1)], wd1 = row[min(w0 + 1, W - 1)], wd2 = row[min(w0 + 2, W - 1)];
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int dpi = dp0 + 16 * mi + rg;
-                const bool hit = ((row[dpi >> 5] >> (dpi & 31)) & 1u) && acc[mi][ni][rg] > -INFINITY;
+                const int off = b0 + 16 * mi + rg;                   // < 32 + 52
+                const uint32_t wd = off < 32 ? wd0 : (off < 64 ? wd1 : wd2);
+                const bool hit = ((wd >> (off & 31)) & 1u) && acc[mi][ni][rg] > -INFINITY;
                 acc[mi][ni][rg] = hit ? __uint_as_float(SUPP_BITS) : acc[mi][ni][rg];
                 any |= hit;
             }
@@ -1306,7 +1329,6 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
         }
         if (tid == 0 && a.stats) atomicAdd(&a.stats[3], 1);
         __syncthreads();
-        PROF_INIT(16);                                               // what follows is counted apart
     }
     // ---- correlations on the fp32 matrix cores ------------------------------------------------------
     corr_tile_gemm(a.bank32t, sl->masks, (L + SLAB - 1) / SLAB, r32 + 64 * wave + lr + lq, slab, acc);
@@ -1327,6 +1349,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
 // A node the fp16 filter cannot settle is flagged (a.flags) and left to mmp_level_kernel in fp32, launched behind.
 #define NG 3
 #define GBLK (NG * BLKF)               // halves of one group-slab in the ring
+#define LRING 4                        // group-slabs in the ring (copies run LRING - 1 steps ahead)
 
 // group-slab s of group g: blocks 3g .. 3g + 2 of slab s, one 1 KiB copy per wave 0..2
 __device__ __forceinline__ void stage_group16(const _Float16* gslab, _Float16* lslab, int g, int wave, int lane) {
@@ -1348,19 +1371,24 @@ __device__ __forceinline__ void gemm16_group(const _Float16* __restrict__ tile, 
     const _Float16* ra = r16 + (lr & 7) * R16_CS + 64 * wave + (lr & 8) + 8 * lq;
     WAIT_VM(0);                                                      // nothing of ours in flight: the counts below hold
 #pragma unroll
-    for (int q = 0; q < RING16 - 1; ++q)
+    for (int q = 0; q < LRING - 1; ++q)
         if (s0 + q < s1) stage_group16(tile + (size_t)(s0 + q) * SLABF, ring + q * GBLK, g, wave, lane);
+    // A fragment (mi + 2, s) is fragment (mi, s + 1) (32 window elements further either way): two of the four
+    // fragments of a slab are carried over from the slab before, two are read
+    f16x8 af[MT];
+    af[0] = *reinterpret_cast<const f16x8*>(ra + 32 * s0);
+    af[1] = *reinterpret_cast<const f16x8*>(ra + 32 * s0 + 16);
     for (int s = s0; s < s1; ++s) {
-        const int later = min(RING16 - 2, s1 - 1 - s);               // one copy per slab and wave (waves 0..2)
-        if (later == 2) WAIT_VM(2); else if (later == 1) WAIT_VM(1); else WAIT_VM(0);
+        const int later = min(LRING - 2, s1 - 1 - s);               // one copy per slab and wave (waves 0..2)
+        if (later >= 3) WAIT_VM(3); else if (later == 2) WAIT_VM(2); else if (later == 1) WAIT_VM(1); else WAIT_VM(0);
         __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));   // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
-        if (s + RING16 - 1 < s1)
-            stage_group16(tile + (size_t)(s + RING16 - 1) * SLABF, ring + ((s - s0 + RING16 - 1) % RING16) * GBLK, g, wave, lane);
-        const _Float16* sb = ring + ((s - s0) % RING16) * GBLK + lane * 8;
-        f16x8 af[MT], bf[NG];
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) af[mi] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 16 * mi);
+        if (s + LRING - 1 < s1)
+            stage_group16(tile + (size_t)(s + LRING - 1) * SLABF, ring + ((s - s0 + LRING - 1) % LRING) * GBLK, g, wave, lane);
+        const _Float16* sb = ring + ((s - s0) % LRING) * GBLK + lane * 8;
+        f16x8 bf[NG];
+        af[2] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 32);
+        af[3] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 48);
 #pragma unroll
         for (int nj = 0; nj < NG; ++nj) bf[nj] = *reinterpret_cast<const f16x8*>(sb + nj * BLKF);
 #pragma unroll
@@ -1368,6 +1396,8 @@ __device__ __forceinline__ void gemm16_group(const _Float16* __restrict__ tile, 
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
                 acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
+        af[0] = af[2];
+        af[1] = af[3];
     }
     __syncthreads();
 }
@@ -1442,10 +1472,10 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
     const int N = a.N, K = a.K, L = a.L, d = a.depth;
     const int nslab = (L + SLAB - 1) / SLAB;
 
-    // ---- LDS carve-up: ring [RING16][GBLK] halves | r64 [Npad] | r16 [R16_COPIES][R16_CS] | NodeLds | LeanLds
+    // ---- LDS carve-up: ring [LRING][GBLK] halves | r64 [Npad] | r16 [R16_COPIES][R16_CS] | NodeLds | LeanLds
     const int Npad = (N + 3) & ~3;
     _Float16* ring = reinterpret_cast<_Float16*>(lds_raw);
-    double* r64 = lds_raw + (RING16 * GBLK) / 4;
+    double* r64 = lds_raw + (LRING * GBLK) / 4;
     _Float16* r16 = reinterpret_cast<_Float16*>(r64 + Npad);
     NodeLds* sl = reinterpret_cast<NodeLds*>(r16 + R16_COPIES * R16_CS);
     LeanLds* ll = reinterpret_cast<LeanLds*>(sl + 1);
@@ -1459,7 +1489,7 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
     if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
     if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
 
-    PROF_INIT(0);
+    PROF_INIT(16);
     const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
     double rnorm2, first[4];
     node_prologue(a, sl, r64, nullptr, Npad, 0, rin, s, j, rnorm2, first);
@@ -2066,7 +2096,7 @@ static size_t flag_ws_bytes(int S, int max_sparsity, const TreeShape& ts) {     
     return ((size_t)S * frontier_max(max_sparsity, ts) + 15) & ~(size_t)15;
 }
 static size_t lean_lds_bytes(int N) {
-    return (size_t)RING16 * GBLK * 2 + (size_t)ceil4(N) * 8 + R16_COPIES * R16_CS * 2 + sizeof(NodeLds) + sizeof(LeanLds);
+    return (size_t)LRING * GBLK * 2 + (size_t)ceil4(N) * 8 + R16_COPIES * R16_CS * 2 + sizeof(NodeLds) + sizeof(LeanLds);
 }
 
 size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections, int branches) {

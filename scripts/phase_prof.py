@@ -22,11 +22,13 @@ torch.cuda.synchronize()
 L.csc_prof_read(buf, 1)
 v = np.array(list(buf), dtype=np.float64)
 names = ["prologue", "gemm", "suppress", "max + candidates", "-", "rescore + choose",
-         "gram dots", "solve", "residual + write", "tail"]
-rows = (("all nodes (level 0: register-resident kernel, levels 1-4: lean kernel unless --no-lean)", 0, 3200 * 13),
-        ("nodes repeated in fp32 after the filter", 16, 3200 * 13))
+         "gram dots", "solve", "residual + write", "tail", "(suppress: wait for the siblings' waves)",
+         "(suppress: similarity row -> LDS)"]
+lean = "--fp32" not in sys.argv and "--no-lean" not in sys.argv
+rows = (("mmp_level_kernel: level 0" + ("" if lean else " - 4"), 0, 3200 if lean else 3200 * 13),
+        ("mmp_level_lean_kernel: levels 1 - 4 (gemm = sweep 1, max + candidates = sweep 2)", 16, 3200 * 12 if lean else 1))
 for title, base, nodes in rows:
-    w = v[base:base + 10]
+    w = v[base:base + 12]
     tot = w.sum()
     print(title)
     for n, x in zip(names, w):
