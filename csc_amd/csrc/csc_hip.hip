@@ -90,7 +90,8 @@ struct LevelArgs {
     const _Float16* bank16;  // the bank in fp16, blocked like bank32t with (k-group, column, 8 rows) fragments
     const float* amax2;   // max_k ||a_k||^2 (scales the fp16 error bound)
     const double* anorm2; // [K] ||a_k||^2
-    uint8_t* flags;       // [S][F[d]] lean kernel -> mmp_level_kernel: 1 = this node still has to be done (in fp32)
+    uint8_t* flags;       // [S][F[d]] lean kernel -> follow-up kernel: 1 = this node still has to be done (in fp32)
+    int S;                // signals
     TreeShape ts;
 };
 
@@ -1295,7 +1296,6 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     size_t s;
     int j;
     node_of_block(Fd, s, j);
-    if (a.flags && !a.flags[s * Fd + j]) return;                      // settled by the lean kernel
     const int nch = children_of(a, j);
     if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
     if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
@@ -1338,6 +1338,49 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     PROF_MARK(9);
 }
 
+// ---- follow-up of the lean kernel: the nodes it flagged, in fp32 --------------------------------------------
+// Usually nothing is flagged, so the launch should cost as little as possible: a workgroup looks at FOLLOW_NODES
+// consecutive nodes (an eighth of the workgroups to dispatch) and runs the flagged ones one after the other.
+#define FOLLOW_NODES 8
+__global__ __launch_bounds__(WG, 2) void mmp_level_followup_kernel(const LevelArgs a) {
+    extern __shared__ double lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int N = a.N, L = a.L, Lp = a.Lp, d = a.depth;
+    const int Npad = (N + 3) & ~3;
+    const int R32 = CSC_TILE_ROWS + Lp + 4;
+    float* slab = reinterpret_cast<float*>(lds_raw);
+    uint32_t* simrow = reinterpret_cast<uint32_t*>(slab);
+    double* r64 = lds_raw + SLABF;
+    float* r32 = reinterpret_cast<float*>(r64 + Npad);
+    _Float16* r16 = reinterpret_cast<_Float16*>(r32 + ((R32 + 3) & ~3));           // unused here; same carve-up
+    NodeLds* sl = reinterpret_cast<NodeLds*>(r16 + R16_COPIES * R16_CS);
+    const int Fd = a.ts.F[d];
+    const size_t total = (size_t)a.S * Fd;
+    bool meta_loaded = false;
+    for (int q = 0; q < FOLLOW_NODES; ++q) {
+        const size_t nl = (size_t)blockIdx.x * FOLLOW_NODES + q;
+        if (nl >= total) break;
+        if (!a.flags[nl]) continue;                                   // workgroup-uniform
+        if (!meta_loaded) {
+            if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
+            if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
+            meta_loaded = true;
+        }
+        const size_t s = nl / Fd;
+        const int j = (int)(nl - s * Fd);
+        const int nch = children_of(a, j);
+        PROF_INIT(0);
+        const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
+        double rnorm2, first[4];
+        const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2, first);
+        f32x4 acc[MT][NT];
+        corr_tile_gemm(a.bank32t, sl->masks, (L + SLAB - 1) / SLAB, r32 + 64 * wave + lr + lq, slab, acc);
+        select_children<true>(a, sl, r64, simrow, s, j, nch, delta, acc);
+        __syncthreads();
+    }
+}
+
 // ---- the lean level kernel: the same node, three column groups at a time ----------------------------------
 // mmp_level_kernel keeps the whole (256 x 144) correlation matrix in registers, 144 VGPRs per lane, which allows
 // two nodes per CU -- and a node is a chain of short dependent steps, so the CU idles.  A node does not need the
@@ -1346,7 +1389,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
 // group's maximum (after suppression by the earlier siblings, read from the similarity table), sweep 2 collects
 // the candidates from the groups that reach the band, recomputing them -- 4/3 of the MFMA work, a third of the
 // registers, LDS for four nodes per CU.  Everything behind the candidates is the shared code.
-// A node the fp16 filter cannot settle is flagged (a.flags) and left to mmp_level_kernel in fp32, launched behind.
+// A node the fp16 filter cannot settle is flagged (a.flags) and left to mmp_level_followup_kernel (fp32), launched behind.
 #define NG 3
 #define GBLK (NG * BLKF)               // halves of one group-slab in the ring
 #define LRING 4                        // group-slabs in the ring (copies run LRING - 1 steps ahead)
@@ -2146,6 +2189,8 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
     clear_stale_error();
     hipFuncSetAttribute(tiled ? (const void*)mmp_level_tiled_kernel : (const void*)mmp_level_kernel,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!tiled) hipFuncSetAttribute((const void*)mmp_level_followup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds);
 
     double* ws[2] = {static_cast<double*>(d_workspace), static_cast<double*>(d_workspace) + node_bytes / 16};
     hipStream_t st = (hipStream_t)stream;
@@ -2165,7 +2210,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         const size_t grid = (size_t)S * ts.F[d];
         if (grid > 0x7fffffffULL) FAIL(-11, "batch too large for one launch (%zu workgroups)", grid);
         const int span = timer_begin(st, d);
-        a.flags = nullptr;
+        a.flags = nullptr; a.S = S;
         if (tiled) {
             hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
         } else if (lean && grid > 512 && (connections == 1 || ts.pw[d] >= ts.F[d + 1])) {
@@ -2174,8 +2219,8 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
             // 512 nodes or fewer are all resident at once on either kernel
             a.flags = node_flags;
             hipLaunchKernelGGL(mmp_level_lean_kernel, dim3((unsigned)grid), dim3(WG), lean_lds_bytes(N), st, a);
-            a.bank16 = nullptr;                                      // what it flagged: fp32
-            hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
+            hipLaunchKernelGGL(mmp_level_followup_kernel, dim3((unsigned)((grid + FOLLOW_NODES - 1) / FOLLOW_NODES)),
+                               dim3(WG), lds, st, a);                // what it flagged: fp32
         } else {
             hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
         }
