@@ -49,7 +49,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 8-byte access
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define R16_COPIES 8                   // fp16 residual window: copy c holds r[i + c], so every 8-element Hankel
-#define R16_CS 776                     // fragment is one aligned 16-byte LDS read; copy stride = 16 mod 128 bytes
+#define R16_CS 800                     // fragment is one aligned 16-byte LDS read.  Copy stride = 64 mod 256 bytes:
+                                       // the 12 distinct addresses of each 16-lane group of a ds_read_b128 (window
+                                       // elements e..e+3, e+12..e+19) then fall on 12 different 16-byte bank slots
 
 // Development aid (make prof): per-phase shader-clock totals of the level kernels, summed over workgroups
 // (slots 0-15: mmp_level_kernel / the tiled kernel, 16-31: mmp_level_lean_kernel; scripts/phase_prof.py names them).
