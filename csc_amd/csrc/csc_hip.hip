@@ -1394,7 +1394,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_followup_kernel(const LevelAr
 // A node the fp16 filter cannot settle is flagged (a.flags) and left to mmp_level_followup_kernel (fp32), launched behind.
 #define NG 3
 #define GBLK (NG * BLKF)               // halves of one group-slab in the ring
-#define LRING 4                        // group-slabs in the ring (copies run LRING - 1 steps ahead)
+#define LRING 5                        // group-slabs in the ring: two being read, three copies ahead
 
 // group-slab s of group g: blocks 3g .. 3g + 2 of slab s, one 1 KiB copy per wave 0..2
 __device__ __forceinline__ void stage_group16(const _Float16* gslab, _Float16* lslab, int g, int wave, int lane) {
@@ -1416,21 +1416,15 @@ __device__ __forceinline__ void gemm16_group(const _Float16* __restrict__ tile, 
     const _Float16* ra = r16 + (lr & 7) * R16_CS + 64 * wave + (lr & 8) + 8 * lq;
     WAIT_VM(0);                                                      // nothing of ours in flight: the counts below hold
 #pragma unroll
-    for (int q = 0; q < LRING - 1; ++q)
+    for (int q = 0; q < 3; ++q)
         if (s0 + q < s1) stage_group16(tile + (size_t)(s0 + q) * SLABF, ring + q * GBLK, g, wave, lane);
     // A fragment (mi + 2, s) is fragment (mi, s + 1) (32 window elements further either way): two of the four
     // fragments of a slab are carried over from the slab before, two are read
     f16x8 af[MT];
     af[0] = *reinterpret_cast<const f16x8*>(ra + 32 * s0);
     af[1] = *reinterpret_cast<const f16x8*>(ra + 32 * s0 + 16);
-    for (int s = s0; s < s1; ++s) {
-        const int later = min(LRING - 2, s1 - 1 - s);               // one copy per slab and wave (waves 0..2)
-        if (later >= 3) WAIT_VM(3); else if (later == 2) WAIT_VM(2); else if (later == 1) WAIT_VM(1); else WAIT_VM(0);
-        __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));   // lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        if (s + LRING - 1 < s1)
-            stage_group16(tile + (size_t)(s + LRING - 1) * SLABF, ring + ((s - s0 + LRING - 1) % LRING) * GBLK, g, wave, lane);
-        const _Float16* sb = ring + ((s - s0) % LRING) * GBLK + lane * 8;
+    auto slab = [&](int s, int slot) {
+        const _Float16* sb = ring + slot * GBLK + lane * 8;
         f16x8 bf[NG];
         af[2] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 32);
         af[3] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 48);
@@ -1443,6 +1437,21 @@ __device__ __forceinline__ void gemm16_group(const _Float16* __restrict__ tile, 
                 acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
         af[0] = af[2];
         af[1] = af[3];
+    };
+    // Two slabs per barrier: at the top of a pair slabs s and s + 1 have landed (slab s + 2 may be in flight),
+    // and the two ring slots of the pair before are free for the copies of slabs s + 3 and s + 4.
+    int slot = 0;
+    for (int s = s0; s < s1; s += 2) {
+        if (s + 2 < s1) WAIT_VM(1); else WAIT_VM(0);                 // one copy per slab and wave (waves 0..2)
+        __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));   // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        const int sl3 = slot + 3 >= LRING ? slot + 3 - LRING : slot + 3, sl4 = sl3 + 1 >= LRING ? sl3 + 1 - LRING : sl3 + 1;
+        if (s + 3 < s1) stage_group16(tile + (size_t)(s + 3) * SLABF, ring + sl3 * GBLK, g, wave, lane);
+        if (s + 4 < s1) stage_group16(tile + (size_t)(s + 4) * SLABF, ring + sl4 * GBLK, g, wave, lane);
+        slab(s, slot);
+        const int sl1 = slot + 1 >= LRING ? slot + 1 - LRING : slot + 1;
+        if (s + 1 < s1) slab(s + 1, sl1);
+        slot = sl1 + 1 >= LRING ? sl1 + 1 - LRING : sl1 + 1;
     }
     __syncthreads();
 }
