@@ -1423,18 +1423,20 @@ __device__ __forceinline__ void gemm16_group(const _Float16* __restrict__ tile, 
     f16x8 af[MT];
     af[0] = *reinterpret_cast<const f16x8*>(ra + 32 * s0);
     af[1] = *reinterpret_cast<const f16x8*>(ra + 32 * s0 + 16);
+#define LEAN_MFMA(A, B, mi, nj) acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc[mi][nj], 0, 0, 0)
     auto slab = [&](int s, int slot) {
         const _Float16* sb = ring + slot * GBLK + lane * 8;
         f16x8 bf[NG];
+#pragma unroll
+        for (int nj = 0; nj < NG; ++nj) bf[nj] = *reinterpret_cast<const f16x8*>(sb + nj * BLKF);
         af[2] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 32);
         af[3] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 48);
 #pragma unroll
-        for (int nj = 0; nj < NG; ++nj) bf[nj] = *reinterpret_cast<const f16x8*>(sb + nj * BLKF);
+        for (int mh = 0; mh < MT; mh += 2)                           // the carried fragments first
 #pragma unroll
-        for (int nj = 0; nj < NG; ++nj)
+            for (int nj = 0; nj < NG; ++nj)
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-                acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
+                for (int mi = mh; mi < mh + 2; ++mi) LEAN_MFMA(af[mi], bf[nj], mi, nj);
         af[0] = af[2];
         af[1] = af[3];
     };
@@ -1448,8 +1450,8 @@ __device__ __forceinline__ void gemm16_group(const _Float16* __restrict__ tile, 
         const int sl3 = slot + 3 >= LRING ? slot + 3 - LRING : slot + 3, sl4 = sl3 + 1 >= LRING ? sl3 + 1 - LRING : sl3 + 1;
         if (s + 3 < s1) stage_group16(tile + (size_t)(s + 3) * SLABF, ring + sl3 * GBLK, g, wave, lane);
         if (s + 4 < s1) stage_group16(tile + (size_t)(s + 4) * SLABF, ring + sl4 * GBLK, g, wave, lane);
-        slab(s, slot);
         const int sl1 = slot + 1 >= LRING ? slot + 1 - LRING : slot + 1;
+        slab(s, slot);
         if (s + 1 < s1) slab(s + 1, sl1);
         slot = sl1 + 1 >= LRING ? sl1 + 1 - LRING : sl1 + 1;
     }
