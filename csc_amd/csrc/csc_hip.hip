@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <type_traits>
 
 #include "../../include/csc_hip.h"
 
@@ -1419,26 +1420,27 @@ __device__ __forceinline__ void gemm16_group(const _Float16* __restrict__ tile, 
     for (int q = 0; q < 3; ++q)
         if (s0 + q < s1) stage_group16(tile + (size_t)(s0 + q) * SLABF, ring + q * GBLK, g, wave, lane);
     // A fragment (mi + 2, s) is fragment (mi, s + 1) (32 window elements further either way): two of the four
-    // fragments of a slab are carried over from the slab before, two are read
+    // fragments of a slab are carried over from the slab before; the other two are requested one slab ahead, into
+    // the registers of the pair that has just been used for the last time (X and Y swap roles every slab)
     f16x8 af[MT];
     af[0] = *reinterpret_cast<const f16x8*>(ra + 32 * s0);
     af[1] = *reinterpret_cast<const f16x8*>(ra + 32 * s0 + 16);
+    af[2] = *reinterpret_cast<const f16x8*>(ra + 32 * s0 + 32);
+    af[3] = *reinterpret_cast<const f16x8*>(ra + 32 * s0 + 48);
 #define LEAN_MFMA(A, B, mi, nj) acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc[mi][nj], 0, 0, 0)
-    auto slab = [&](int s, int slot) {
+    // X = af[x0], af[x0 + 1] hold row tiles 0, 1 of slab s, Y = the other two hold row tiles 2, 3
+    auto slab = [&](int s, int slot, auto xc) {
+        constexpr int x0 = decltype(xc)::value, y0 = 2 - x0;
         const _Float16* sb = ring + slot * GBLK + lane * 8;
         f16x8 bf[NG];
 #pragma unroll
         for (int nj = 0; nj < NG; ++nj) bf[nj] = *reinterpret_cast<const f16x8*>(sb + nj * BLKF);
-        af[2] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 32);
-        af[3] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 48);
 #pragma unroll
-        for (int mh = 0; mh < MT; mh += 2)                           // the carried fragments first
+        for (int nj = 0; nj < NG; ++nj) { LEAN_MFMA(af[x0], bf[nj], 0, nj); LEAN_MFMA(af[x0 + 1], bf[nj], 1, nj); }
+        af[x0] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 64);          // row tiles 2, 3 of slab s + 1
+        af[x0 + 1] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 80);      // (inside the copy for s + 1 = 16 too)
 #pragma unroll
-            for (int nj = 0; nj < NG; ++nj)
-#pragma unroll
-                for (int mi = mh; mi < mh + 2; ++mi) LEAN_MFMA(af[mi], bf[nj], mi, nj);
-        af[0] = af[2];
-        af[1] = af[3];
+        for (int nj = 0; nj < NG; ++nj) { LEAN_MFMA(af[y0], bf[nj], 2, nj); LEAN_MFMA(af[y0 + 1], bf[nj], 3, nj); }
     };
     // Two slabs per barrier: at the top of a pair slabs s and s + 1 have landed (slab s + 2 may be in flight),
     // and the two ring slots of the pair before are free for the copies of slabs s + 3 and s + 4.
@@ -1451,8 +1453,8 @@ __device__ __forceinline__ void gemm16_group(const _Float16* __restrict__ tile, 
         if (s + 3 < s1) stage_group16(tile + (size_t)(s + 3) * SLABF, ring + sl3 * GBLK, g, wave, lane);
         if (s + 4 < s1) stage_group16(tile + (size_t)(s + 4) * SLABF, ring + sl4 * GBLK, g, wave, lane);
         const int sl1 = slot + 1 >= LRING ? slot + 1 - LRING : slot + 1;
-        slab(s, slot);
-        if (s + 1 < s1) slab(s + 1, sl1);
+        slab(s, slot, std::integral_constant<int, 0>{});
+        if (s + 1 < s1) slab(s + 1, sl1, std::integral_constant<int, 2>{});
         slot = sl1 + 1 >= LRING ? sl1 + 1 - LRING : sl1 + 1;
     }
     __syncthreads();
