@@ -1429,18 +1429,28 @@ __device__ __forceinline__ void gemm16_group(const _Float16* __restrict__ tile, 
     af[3] = *reinterpret_cast<const f16x8*>(ra + 32 * s0 + 48);
 #define LEAN_MFMA(A, B, mi, nj) acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc[mi][nj], 0, 0, 0)
     // X = af[x0], af[x0 + 1] hold row tiles 0, 1 of slab s, Y = the other two hold row tiles 2, 3
-    auto slab = [&](int s, int slot, auto xc) {
+    // `first`: the slab's B fragments are read here (first slab behind a barrier); `pref`: the B fragments
+    // of the pair's second slab (ring slot `next`) are requested behind the last use of this slab's
+    f16x8 bf[NG];
+    auto slab = [&](int s, int slot, auto xc, auto firstc, auto prefc, int next) {
         constexpr int x0 = decltype(xc)::value, y0 = 2 - x0;
+        constexpr bool first = decltype(firstc)::value, pref = decltype(prefc)::value;
         const _Float16* sb = ring + slot * GBLK + lane * 8;
-        f16x8 bf[NG];
+        if (first) {
 #pragma unroll
-        for (int nj = 0; nj < NG; ++nj) bf[nj] = *reinterpret_cast<const f16x8*>(sb + nj * BLKF);
+            for (int nj = 0; nj < NG; ++nj) bf[nj] = *reinterpret_cast<const f16x8*>(sb + nj * BLKF);
+        }
 #pragma unroll
         for (int nj = 0; nj < NG; ++nj) { LEAN_MFMA(af[x0], bf[nj], 0, nj); LEAN_MFMA(af[x0 + 1], bf[nj], 1, nj); }
         af[x0] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 64);          // row tiles 2, 3 of slab s + 1
         af[x0 + 1] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 80);      // (inside the copy for s + 1 = 16 too)
+        const _Float16* sn = ring + next * GBLK + lane * 8;
 #pragma unroll
-        for (int nj = 0; nj < NG; ++nj) { LEAN_MFMA(af[y0], bf[nj], 2, nj); LEAN_MFMA(af[y0 + 1], bf[nj], 3, nj); }
+        for (int nj = 0; nj < NG; ++nj) {
+            LEAN_MFMA(af[y0], bf[nj], 2, nj);
+            LEAN_MFMA(af[y0 + 1], bf[nj], 3, nj);
+            if (pref) bf[nj] = *reinterpret_cast<const f16x8*>(sn + nj * BLKF);
+        }
     };
     // Two slabs per barrier: at the top of a pair slabs s and s + 1 have landed (slab s + 2 may be in flight),
     // and the two ring slots of the pair before are free for the copies of slabs s + 3 and s + 4.
@@ -1453,8 +1463,9 @@ __device__ __forceinline__ void gemm16_group(const _Float16* __restrict__ tile, 
         if (s + 3 < s1) stage_group16(tile + (size_t)(s + 3) * SLABF, ring + sl3 * GBLK, g, wave, lane);
         if (s + 4 < s1) stage_group16(tile + (size_t)(s + 4) * SLABF, ring + sl4 * GBLK, g, wave, lane);
         const int sl1 = slot + 1 >= LRING ? slot + 1 - LRING : slot + 1;
-        slab(s, slot, std::integral_constant<int, 0>{});
-        if (s + 1 < s1) slab(s + 1, sl1, std::integral_constant<int, 2>{});
+        // (at an odd end the request for the missing second slab reads a ring slot nobody waits for: unused)
+        slab(s, slot, std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{}, sl1);
+        if (s + 1 < s1) slab(s + 1, sl1, std::integral_constant<int, 2>{}, std::false_type{}, std::false_type{}, 0);
         slot = sl1 + 1 >= LRING ? sl1 + 1 - LRING : sl1 + 1;
     }
     __syncthreads();
