@@ -18,7 +18,7 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
 
-KERNELS = ("mmp_level_lean_kernel", "mmp_level_kernel")     # levels 1-4 (+ their fp32 follow-up launch) / level 0
+KERNELS = ("mmp_level_lean_kernel", "mmp_level_followup_kernel", "mmp_level_kernel")   # levels 1-4, their fp32 follow-up / level 0
 summary = {"kernels": KERNELS,
            "command": "rocprofv3 --pmc <group> -- python3 bench.py --no-cpu-baseline --no-fp32-leg --steps 10 --warmup 2",
            "per_kernel": {}}
@@ -35,9 +35,7 @@ for group in ("pmc_fetch", "pmc_write", "pmc_sq"):
         k = next((k for k in KERNELS if name.startswith(k)), None)
         if k is None:
             continue
-        # the fp32 follow-up launches of mmp_level_kernel behind the lean kernel find nothing to do: counted in
-        # the traffic total, kept out of the level-0 averages (they run the full grid of the level, 9600 nodes)
-        key = k if not (k == "mmp_level_kernel" and int(row["Grid_Size"]) > 3200 * 256) else "mmp_level_kernel (follow-up)"
+        key = k
         acc.setdefault(key, defaultdict(list))[row["Counter_Name"]].append(float(row["Counter_Value"]))
         if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             totals[row["Counter_Name"]] += float(row["Counter_Value"])
