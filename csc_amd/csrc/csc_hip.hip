@@ -1343,8 +1343,9 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
 
 // ---- follow-up of the lean kernel: the nodes it flagged, in fp32 --------------------------------------------
 // Usually nothing is flagged, so the launch should cost as little as possible: a workgroup looks at FOLLOW_NODES
-// consecutive nodes (an eighth of the workgroups to dispatch) and runs the flagged ones one after the other.
-#define FOLLOW_NODES 8
+// consecutive nodes (a sixteenth of the workgroups to dispatch, their flags in one load) and runs the flagged ones
+// one after the other.
+#define FOLLOW_NODES 16
 __global__ __launch_bounds__(WG, 2) void mmp_level_followup_kernel(const LevelArgs a) {
     extern __shared__ double lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1361,10 +1362,14 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_followup_kernel(const LevelAr
     const int Fd = a.ts.F[d];
     const size_t total = (size_t)a.S * Fd;
     bool meta_loaded = false;
+    // the workgroup's 16 flag bytes in one round trip (the buffer is padded to a multiple of 16 bytes)
+    const uint64_t* fw = reinterpret_cast<const uint64_t*>(a.flags + (size_t)blockIdx.x * FOLLOW_NODES);
+    const uint64_t f0 = fw[0], f1 = fw[1];
+    if (!(f0 | f1)) return;
     for (int q = 0; q < FOLLOW_NODES; ++q) {
         const size_t nl = (size_t)blockIdx.x * FOLLOW_NODES + q;
         if (nl >= total) break;
-        if (!a.flags[nl]) continue;                                   // workgroup-uniform
+        if (!(((q < 8 ? f0 : f1) >> (8 * (q & 7))) & 0xff)) continue;    // workgroup-uniform
         if (!meta_loaded) {
             if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
             if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
