@@ -846,7 +846,9 @@ __device__ __forceinline__ float node_prologue(const LevelArgs& a, NodeLds* sl, 
 // with value 0; on candidate overflow the fp32 arg-max (sl->widx) is taken.  Writes sl->sup_pos/atom[d].
 __device__ __forceinline__ void rescore_and_choose(const LevelArgs& a, NodeLds* sl, const double* r64,
                                                    int ncand_raw, bool zero_band) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                                   // see child_solve_and_write
+    const int lane = tid & 63, wave = tid >> 6;
     const int K = a.K, L = a.L, d = a.depth;
     const int ncand = min(ncand_raw, CAND_CAP);
     for (int c = 2 * wave; c < ncand; c += 2 * (WG / 64)) {          // two candidates per wave and round trip
@@ -897,7 +899,11 @@ __device__ __forceinline__ void rescore_and_choose(const LevelArgs& a, NodeLds* 
 // (pos, atom) -> node tables.
 __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLds* sl, const double* r64,
                                                       size_t s, int jc, size_t cid) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the thread index goes through an opaque move: otherwise the 64-bit per-lane address parts derived from it are
+    // hoisted above the node's GEMM loops and live (spilled to scratch, i.e. to HBM) until here
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int N = a.N, L = a.L, d = a.depth;
     const int p_sel = sl->sup_pos[d], k_sel = sl->sup_atom[d];
     const int Fc = a.ts.F[d + 1];
@@ -1534,7 +1540,7 @@ __device__ __forceinline__ float group_finish(const LevelArgs& a, const NodeLds*
 }
 
 struct LeanLds {
-    float gmax[NT / NG];
+    float wgmax[NT / NG][WG / 64];     // sweep 1: maximum of each group per wave
     int sib_pos[CSC_MAX_CONNECTIONS], sib_atom[CSC_MAX_CONNECTIONS];
     int s0[NT / NG], s1[NT / NG];      // slab range of each group (outside it the group's blocks are zero padding)
 };
@@ -1598,23 +1604,24 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
             gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
             const float lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, t, permv, acc, lane_supp);
             const float bv = wave_max(lane_supp ? fmaxf(lmax, 0.f) : lmax);
-            if (lane == 63) sl->wmax[wave] = bv;
-            __syncthreads();
-            if (tid == 0) ll->gmax[g] = fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
-            __syncthreads();
+            if (lane == 63) ll->wgmax[g][wave] = bv;                  // read behind the barrier below
         }
-        PROF_MARK(1);
-        const float m32 = fmaxf(fmaxf(ll->gmax[0], ll->gmax[1]), ll->gmax[2]);
-        const float tau = m32 - band;
         if (tid == 0) sl->cand_cnt = 0;
         __syncthreads();
+        float gmax[NT / NG];
+#pragma unroll
+        for (int g = 0; g < NT / NG; ++g)
+            gmax[g] = fmaxf(fmaxf(ll->wgmax[g][0], ll->wgmax[g][1]), fmaxf(ll->wgmax[g][2], ll->wgmax[g][3]));
+        PROF_MARK(1);
+        const float m32 = fmaxf(fmaxf(gmax[0], gmax[1]), gmax[2]);
+        const float tau = m32 - band;
         if (0.f >= tau && t > 0) {                 // the value 0 of suppressed entries may compete: fp32 launch
             if (tid == 0) { a.flags[s * Fd + j] = 1; if (a.stats) atomicAdd(&a.stats[3], 1); }
             return;
         }
         // ---- sweep 2: candidates from the groups that reach the band; the last group is still in registers --
         for (int g = 0; g < NT / NG; ++g) {
-            if (!(ll->gmax[g] >= tau)) continue;                      // uniform
+            if (!(gmax[g] >= tau)) continue;                          // uniform
             bool lane_supp;
             float lmax;
             if (g != 0) {
