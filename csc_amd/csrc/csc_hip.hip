@@ -2238,7 +2238,9 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         a.K = K; a.L = L; a.Lp = Lp; a.N = N; a.P = P; a.W = W;
         a.depth = d; a.Kmax = max_sparsity; a.connections = connections; a.NN = NN;
         a.NS = N + TRI(max_sparsity) + max_sparsity; a.mode = mode;
-        a.bank16 = (!tiled && !(flags & CSC_FLAG_FP32_ONLY)) ? bank_tiles16(d_bank32t, K, L) : nullptr;
+        // the fp16 filter's LDS copies hold a window of R16_CS = 256 + 512 + ... elements: atoms of up to 512 samples
+        // (whole slabs); longer atoms correlate in fp32
+        a.bank16 = (!tiled && !(flags & CSC_FLAG_FP32_ONLY) && Lp <= 512) ? bank_tiles16(d_bank32t, K, L) : nullptr;
         a.amax2 = bank_amax2(d_bank32t, K, L);
         a.anorm2 = bank_anorm2(d_bank32t, K, L);
         a.resid_in = (d == 0) ? d_signals : ws[d & 1];

@@ -369,6 +369,48 @@ def test_odd_shapes_vs_oracle():
                 assert abs(res.node_mse[s, nid] - mse) <= 1e-9 * mse + 1e-30
 
 
+@pytest.mark.gpu
+def test_long_atoms_vs_oracle():
+    """atoms longer than 512 samples (592 and 736): beyond the window the fp16 filter's LDS copies hold, so every
+    variant must correlate in fp32 there -- same trees from all three, equal to the oracle's"""
+    import csc_amd
+    from oracle import csc_oracle as O
+    rng = np.random.default_rng(77)
+    for ys in ([0.02, 0.05, 0.06], [0.03, 0.08]):
+        b = [0.005, 0.03]
+        d = csc_amd.ZSDictionary.from_values(b, ys, [1])
+        od = O.OracleDictionary(b, ys, [1])
+        K, L = od.bank.shape
+        assert L > 544
+        P = 200
+        N = L + P - 1
+        S = 600
+        sigs = 0.05 * rng.standard_normal((S, N))
+        for s in range(S):
+            for _ in range(3):
+                p = int(rng.integers(0, P))
+                sigs[s, p:p + L] += rng.uniform(0.3, 1.0) * od.bank[int(rng.integers(K))]
+        bank = d.device_bank()
+        out = {}
+        for name, fp32_only, lean in (("lean", False, True), ("resident", False, False), ("fp32", True, True)):
+            bank.fp32_only, bank.lean = fp32_only, lean
+            out[name] = bank.mmpdf_batch(sigs, 4, 2, 3, 0.8, want_coef=True)
+            assert out[name].stats[0] == 0
+        for name in ("resident", "fp32"):
+            assert np.array_equal(out[name].node_pos, out["lean"].node_pos), (name, L)
+            assert np.array_equal(out[name].node_atom, out["lean"].node_atom), (name, L)
+        res = out["lean"]
+        for s in range(0, S, 100):
+            t = O.OracleTree(od, sigs[s], 4, 2, 0.8, "direct")
+            t.run(3)
+            for path, (pos, atom, mse) in t.all_nodes().items():
+                digits = [int(x) for x in path.split("-")]
+                nid = res.node_id(len(digits), sum((o - 1) * 2 ** i for i, o in enumerate(digits)))
+                assert (int(res.node_pos[s, nid]), int(res.node_atom[s, nid])) == (pos, atom), (L, s, path)
+                assert abs(res.node_mse[s, nid] - mse) <= 1e-9 * mse + 1e-30
+
+
+@pytest.mark.gpu
 def test_random_shapes_all_variants_agree():
     """random dictionaries (6-120 atoms, atom lengths not multiples of 32), signal lengths (1-256 positions) and tree
     shapes: the lean fp16 kernel, the register-resident fp16 kernel and the fp32-only path give the same trees, and
