@@ -2218,6 +2218,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
                       !(flags & CSC_FLAG_NO_LEAN);
     if (max_sparsity > 1 && (workspace_bytes < need || !d_workspace))
         FAIL(-10, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    if (((uintptr_t)d_workspace & 15) != 0) FAIL(-10, "workspace must be 16-byte aligned");
     const int Lp = n_slabs(L) * SLAB;                      // residual window zero-padded to whole slabs
     const int W = csc_sim_words(N, L);
     size_t lds = level_lds_bytes(N, Lp);

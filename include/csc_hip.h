@@ -102,8 +102,8 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
  *               to the fp32 arg-max (candidate overflow), [1] re-selected activations (dead Cholesky
  *               columns), [2] number of fp64 re-scored candidates, [3] nodes the fp16 filter could not
  *               settle (multiplied again in fp32)
- *   workspace   csc_mmpdf_workspace_bytes(...) bytes: two generations of node residuals + one flag byte per
- *               frontier node
+ *   workspace   csc_mmpdf_workspace_bytes(...) bytes, 16-byte aligned (hipMalloc's are): two generations of node
+ *               residuals + one flag byte per frontier node
  */
 int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
                     int K, int L, const double* d_signals, int S, int N,

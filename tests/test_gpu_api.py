@@ -155,6 +155,22 @@ def test_abi_error_paths(dic):
     # empty batch is a no-op
     res = bank.mmpdf_batch(np.zeros((0, 738)), 3, 3, 3, 0.8)
     assert res.node_pos.shape == (0, 9)
+    # workspace: too small / not 16-byte aligned are argument errors, nothing is launched
+    import torch
+    d = torch.zeros((2, 738), dtype=torch.float64, device="cuda")
+    out = bank.mmpdf_launch(d, 3, 3, 3, 0.8)
+    good = out["ws"]
+    out["ws"] = good[:good.numel() // 2]
+    with pytest.raises(_lib.CscHipError, match="workspace too small"):
+        bank.mmpdf_launch(d, 3, 3, 3, 0.8, out=out)
+    big = torch.empty(good.numel() + 1, dtype=torch.float64, device="cuda")
+    out["ws"] = big[1:]
+    assert out["ws"].data_ptr() % 16 == 8
+    with pytest.raises(_lib.CscHipError, match="16-byte aligned"):
+        bank.mmpdf_launch(d, 3, 3, 3, 0.8, out=out)
+    out["ws"] = good
+    bank.mmpdf_launch(d, 3, 3, 3, 0.8, out=out)
+    torch.cuda.synchronize()
 
 
 def test_zero_signal_edge_case(dic):
