@@ -123,3 +123,28 @@ def test_random_tiled_shapes_vs_oracle():
             t = O.OracleTree(od, sigs[s], Kx, c, 0.75, "direct")
             t.run(B)
             _check_nodes(res, s, {k: v for k, v in t.all_nodes().items()}, c)
+
+
+def test_chunked_batch_is_position_invariant():
+    """BASELINE config 5's shape (far more signals than one device call takes): 70 000 signals = the 3200 config-2
+    signals repeated, through mmpdfSparVarBatch, which cuts them into calls of 32 768.  A signal's records must not
+    depend on where in the batch (which call, which workgroup, next to which neighbours) it sits: every repetition
+    equals the first, and the first 3200 equal a plain 3200-signal call."""
+    import bench
+    dic = bench.canonical_dictionary()
+    base = bench.make_signals(dic, 0)
+    S0 = len(base)
+    n = 70_000
+    sig = np.empty((n, base.shape[1]))
+    for c0 in range(0, n, S0):
+        sig[c0:min(n, c0 + S0)] = base[:min(n, c0 + S0) - c0]
+    big = dic.mmpdfSparVarBatch(sig, 3, 0.8, 3, 5)
+    ref = dic.mmpdfSparVarBatch(base, 3, 0.8, 3, 5)
+    assert big.mse.shape == (n, 5)
+    for c0 in range(0, n, S0):
+        m = min(n, c0 + S0) - c0
+        assert np.array_equal(big.mse[c0:c0 + m], ref.mse[:m]), c0
+        assert np.array_equal(big.leaf[c0:c0 + m], ref.leaf[:m]), c0
+        assert np.array_equal(big.pos[c0:c0 + m], ref.pos[:m]), c0
+        assert np.array_equal(big.atom[c0:c0 + m], ref.atom[:m]), c0
+    assert big.path(n - 1, 5) == ref.path((n - 1) % S0, 5)
