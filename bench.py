@@ -215,10 +215,13 @@ def main():
     if rank == 0:
         ms_step = elapsed / a.steps * 1e3
         value = world * S * a.steps / elapsed
-        launch_ms = float(np.mean([ms for _, ms in spans]))
-        per_level = {str(d): float(np.mean([ms for lv, ms in spans if lv == d])) for d in range(MAX_SPARSITY)}
+        # a span = the launches of one tree level, or of a whole run of levels when one launch walks the chains
+        # below the branching levels (tagged with its first level); `launch_ms` = level-kernel time per tree level
+        launch_ms = float(sum(ms for _, ms in spans)) / (a.steps * MAX_SPARSITY)
+        per_level = {str(d): float(np.mean([ms for lv, ms in spans if lv == d]))
+                     for d in sorted({lv for lv, _ in spans})}
         # ---- algorithmic flops: every selecting node correlates its residual with all
-        # K atoms at all P shifts, 2*P*K*L flops, n_sel = 13 nodes per signal over the 5 level launches
+        # K atoms at all P shifts, 2*P*K*L flops, n_sel = 13 nodes per signal over the 5 tree levels
         flops_per_launch = S * flops_per_signal / MAX_SPARSITY
         achieved = flops_per_launch / (launch_ms * 1e-3) / 1e12
         # MFMA flops actually issued by the fp16 filter: per slab the column tiles from 6, 3 or 0 on (the kernel's five
@@ -244,7 +247,7 @@ def main():
         issued16 = S * n_sel * blocks16 * 4 * 4 * 16384.0 / MAX_SPARSITY / (launch_ms * 1e-3) / 1e12
         fp32_path = None
         if spans_m:
-            launch_ms_m = float(np.mean([ms for _, ms in spans_m]))
+            launch_ms_m = float(sum(ms for _, ms in spans_m)) / (msteps * MAX_SPARSITY)
             achieved_m = flops_per_launch / (launch_ms_m * 1e-3) / 1e12
             # fp32 MFMA flops issued: blocks holding only the atoms' zero padding are skipped, every other
             # block costs 4 waves x 32 v_mfma_f32_16x16x4_f32 (2048 flop each) per node
@@ -258,7 +261,7 @@ def main():
                              "unit": "TFLOP/s", "frac": achieved_m / FP32_MFMA_PEAK_TFLOPS,
                              "launch_ms_avg": launch_ms_m,
                              "launch_ms_by_level": {str(d): float(np.mean([ms for lv, ms in spans_m if lv == d]))
-                                                    for d in range(MAX_SPARSITY)},
+                                                    for d in sorted({lv for lv, _ in spans_m})},
                              "flops_per_launch": flops_per_launch,
                              "mfma_issued": {"tflops": issued, "frac_of_peak": issued / FP32_MFMA_PEAK_TFLOPS,
                                              "blocks_per_node": blocks, "of_dense_blocks": nslab * 9,
@@ -284,7 +287,8 @@ def main():
                                                               if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP16_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "mmp_level_lean_kernel (levels 1-4) + mmp_level_kernel (level 0)", "launch_ms_avg": launch_ms, "launch_ms_by_level": per_level,
+                         "kernel": "mmp_level_lean_kernel (levels 1-4, one launch) + mmp_level_kernel (level 0)",
+                         "launch_ms_avg": launch_ms, "launch_ms_by_level": per_level,
                          "flops_per_launch": flops_per_launch, "flops_per_signal": flops_per_signal,
                          "launches_timed": len(spans),
                          "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,

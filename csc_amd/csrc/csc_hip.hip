@@ -93,8 +93,11 @@ struct LevelArgs {
     const _Float16* bank16;  // the bank in fp16, blocked like bank32t with (k-group, column, 8 rows) fragments
     const float* amax2;   // max_k ||a_k||^2 (scales the fp16 error bound)
     const double* anorm2; // [K] ||a_k||^2
-    uint8_t* flags;       // [S][F[d]] lean kernel -> follow-up kernel: 1 = this node still has to be done (in fp32)
+    uint8_t* flags;       // [S][F[d]] lean kernel -> follow-up kernel: e + 1 = the chain below this node has to be
+                          // taken up at level e (in fp32), 0 = done
     int S;                // signals
+    const double* signals;    // [S][N]            } the chain kernels walk several levels: level e reads
+    double* ws[2];            // [S][F][NS] each   } signals (e == 0) or ws[e & 1] and writes ws[(e + 1) & 1]
     TreeShape ts;
 };
 
@@ -805,9 +808,9 @@ __device__ __forceinline__ void node_of_block(int Fd, size_t& s, int& j) {
 // factor.  Returns the fp32 candidate band delta = 2^-14 * ||residual|| * max_k ||a_k||.  Ends with a barrier.
 __device__ __forceinline__ float node_prologue(const LevelArgs& a, NodeLds* sl, double* r64, float* r32,
                                                int Npad, int R32, const double* __restrict__ rin, size_t s, int j,
-                                               double& rnorm2_out, double (&first)[4]) {
+                                               double& rnorm2_out, double (&first)[4], int d) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = a.N, d = a.depth;
+    const int N = a.N;
     double ss = 0.0;
     for (int i0 = 0; i0 < max(R32, Npad); i0 += 4 * WG) {              // one sweep fills both copies
         double v[4];
@@ -845,11 +848,11 @@ __device__ __forceinline__ float node_prologue(const LevelArgs& a, NodeLds* sl, 
 // maximum, lowest flattened index on ties; with zero_band the first suppressed index (sl->wsupp) competes
 // with value 0; on candidate overflow the fp32 arg-max (sl->widx) is taken.  Writes sl->sup_pos/atom[d].
 __device__ __forceinline__ void rescore_and_choose(const LevelArgs& a, NodeLds* sl, const double* r64,
-                                                   int ncand_raw, bool zero_band) {
+                                                   int ncand_raw, bool zero_band, int d) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));                                   // see child_solve_and_write
     const int lane = tid & 63, wave = tid >> 6;
-    const int K = a.K, L = a.L, d = a.depth;
+    const int K = a.K, L = a.L;
     const int ncand = min(ncand_raw, CAND_CAP);
     for (int c = 2 * wave; c < ncand; c += 2 * (WG / 64)) {          // two candidates per wave and round trip
         const int i0 = sl->cand_idx[c], i1 = sl->cand_idx[min(c + 1, ncand - 1)];
@@ -895,16 +898,20 @@ __device__ __forceinline__ void rescore_and_choose(const LevelArgs& a, NodeLds* 
 }
 
 // Child jc of the node: least squares of the parent residual on the child's support by extending the
-// parent's Cholesky factor with one row, child residual + factor -> workspace, MSE, coefficients,
-// (pos, atom) -> node tables.
-__device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLds* sl, const double* r64,
-                                                      size_t s, int jc, size_t cid) {
+// parent's Cholesky factor with one row, child residual + factor -> workspace (`rout_base`, the level's output
+// buffer, or nullptr), MSE, coefficients, (pos, atom) -> node tables.
+// `carry` (the chain kernel: the workgroup goes on with this child): the child's residual replaces the parent's in
+// r64 (in place: every element is read and written by the same thread), its factor row and coefficients join
+// sl->Lf / sl->coefpar; the child's sum of squares is left in sl->wsum[0..3].
+__device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLds* sl, double* r64,
+                                                      size_t s, int jc, size_t cid, int d, double* rout_base,
+                                                      bool carry) {
     // the thread index goes through an opaque move: otherwise the 64-bit per-lane address parts derived from it are
     // hoisted above the node's GEMM loops and live (spilled to scratch, i.e. to HBM) until here
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6;
-    const int N = a.N, L = a.L, d = a.depth;
+    const int N = a.N, L = a.L;
     const int p_sel = sl->sup_pos[d], k_sel = sl->sup_atom[d];
     const int Fc = a.ts.F[d + 1];
     if (a.mode == 1) {
@@ -929,13 +936,14 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
         }
         __syncthreads();
         const double dw = sl->g[0];
-        double* rout = a.resid_out ? a.resid_out + (s * Fc + jc) * (size_t)a.NS : nullptr;
+        double* rout = rout_base ? rout_base + (s * Fc + jc) * (size_t)a.NS : nullptr;
         const double* an = a.bank64 + (size_t)k_sel * L;
         double cs = 0.0;
         for (int n = tid; n < N; n += WG) {
             const int o = n - p_sel;
             const double v = r64[n] - (((unsigned)o < (unsigned)L) ? dw * an[o] : 0.0);
             if (rout) rout[n] = v;
+            if (carry) r64[n] = v;
             cs = fma(v, v, cs);
         }
         cs = wave_sum(cs);
@@ -950,6 +958,7 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
             const double cv = tid <= d ? sl->x[tid] : 0.0;
             if (a.node_coef) a.node_coef[cid * a.Kmax + tid] = cv;
             if (rout) rout[N + TRI(a.Kmax) + tid] = cv;
+            if (carry && tid <= d) sl->coefpar[tid] = cv;
         }
         return;
     }
@@ -1014,7 +1023,7 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
     __syncthreads();
     PROF_MARK(7);
     // ---- child residual, factor, MSE ------------------------------------------------------------------
-    double* rout = a.resid_out ? a.resid_out + (s * Fc + jc) * (size_t)a.NS : nullptr;
+    double* rout = rout_base ? rout_base + (s * Fc + jc) * (size_t)a.NS : nullptr;
     double cs = 0.0;
     for (int n0 = 0; n0 < N; n0 += 3 * WG) {
         double v[3];
@@ -1047,11 +1056,13 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
             const int n = n0 + tid + WG * u;
             if (n < N) {
                 if (rout) rout[n] = v[u];
+                if (carry) r64[n] = v[u];
                 cs = fma(v[u], v[u], cs);
             }
         }
     }
     if (rout && tid < TRI(d + 1)) rout[N + tid] = tid < TRI(d) ? sl->Lf[tid] : sl->y[tid - TRI(d)];
+    if (carry && tid <= d) sl->Lf[TRI(d) + tid] = sl->y[tid];
     cs = wave_sum(cs);
     if (lane == 63) sl->wsum[wave] = cs;
     __syncthreads();
@@ -1064,6 +1075,7 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
         const double cv = tid <= d ? sl->x[tid] + (tid < d ? sl->coefpar[tid] : 0.0) : 0.0;
         if (a.node_coef) a.node_coef[cid * a.Kmax + tid] = cv;
         if (rout) rout[N + TRI(a.Kmax) + tid] = cv;
+        if (carry && tid <= d) sl->coefpar[tid] = cv;
     }
     PROF_MARK(8);
 }
@@ -1155,11 +1167,12 @@ __device__ __forceinline__ void suppress_similar(const LevelArgs& a, NodeLds* sl
 // (more than CAND_CAP entries in the band, or the value 0 of suppressed entries inside it): the caller then
 // repeats the node from the start on the fp32 correlations, with identical results.
 template <bool EXACT>
-__device__ __forceinline__ bool select_children(const LevelArgs& a, NodeLds* sl, const double* r64, uint32_t* simrow,
-                                                size_t s, int j, int nch, float band, f32x4 (&acc)[MT][NT]) {
+__device__ __forceinline__ bool select_children(const LevelArgs& a, NodeLds* sl, double* r64, uint32_t* simrow,
+                                                size_t s, int j, int nch, float band, f32x4 (&acc)[MT][NT], int d,
+                                                double* rout_base) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15;
-    const int K = a.K, P = a.P, d = a.depth;
+    const int K = a.K, P = a.P;
     const int stride = a.ts.pw[d];
     const int prow = 64 * wave + 4 * (lane >> 4);  // + 16*mi + rg: position of an entry
     int permv[NT];                                // atom of this lane's column in tile ni (-1 = padding)
@@ -1255,11 +1268,11 @@ __device__ __forceinline__ bool select_children(const LevelArgs& a, NodeLds* sl,
             bi = wave_min(bi);
             if (lane == 0) sl->widx[wave] = bi;
         }
-        rescore_and_choose(a, sl, r64, ncand_raw, EXACT && zero_band);   // the filter gets here only with nothing suppressed
+        rescore_and_choose(a, sl, r64, ncand_raw, EXACT && zero_band, d);   // the filter gets here only with nothing suppressed
         PROF_MARK(5);
         const int jc = j + t * stride;                               // child's index in level d+1
         const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
-        child_solve_and_write(a, sl, r64, s, jc, cid);
+        child_solve_and_write(a, sl, r64, s, jc, cid, d, rout_base, false);
         __syncthreads();
     }
     return true;
@@ -1314,7 +1327,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     if (a.bank16) gemm16_prefetch(a.bank16, (L + SLAB - 1) / SLAB, reinterpret_cast<_Float16*>(slab));
     const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
     double rnorm2, first[4];
-    const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2, first);
+    const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2, first, d);
     PROF_MARK(0);
     f32x4 acc[MT][NT];
     // ---- correlations on the fp16 matrix cores, in units of ||r||, as a filter ------------------------------
@@ -1331,7 +1344,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
         __syncthreads();
         corr_tile_gemm16(a.bank16, sl->masks, (L + SLAB - 1) / SLAB, r16, ring, acc);
         PROF_MARK(1);
-        if (select_children<false>(a, sl, r64, simrow, s, j, nch, 2.f * eps16, acc)) {
+        if (select_children<false>(a, sl, r64, simrow, s, j, nch, 2.f * eps16, acc, d, a.resid_out)) {
             __syncthreads();
             PROF_MARK(9);
             return;
@@ -1342,21 +1355,23 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_kernel(const LevelArgs a) {
     // ---- correlations on the fp32 matrix cores ------------------------------------------------------
     corr_tile_gemm(a.bank32t, sl->masks, (L + SLAB - 1) / SLAB, r32 + 64 * wave + lr + lq, slab, acc);
     PROF_MARK(1);
-    select_children<true>(a, sl, r64, simrow, s, j, nch, delta, acc);
+    select_children<true>(a, sl, r64, simrow, s, j, nch, delta, acc, d, a.resid_out);
     __syncthreads();
     PROF_MARK(9);
 }
 
-// ---- follow-up of the lean kernel: the nodes it flagged, in fp32 --------------------------------------------
+// ---- follow-up of the lean kernel: the chains it gave up, in fp32 -----------------------------------------------
 // Usually nothing is flagged, so the launch should cost as little as possible: a workgroup looks at FOLLOW_NODES
-// consecutive nodes (a sixteenth of the workgroups to dispatch, their flags in one load) and runs the flagged ones
-// one after the other.
+// consecutive chains (a sixteenth of the workgroups to dispatch, their flags in one load) and runs the flagged
+// ones one after the other: flag e + 1 = from level e down to the leaves, level by level through the workspace
+// like the per-level launches (the lean kernel left the residual, factor and coefficients of the level-e node in
+// its row of ws[e & 1]).
 #define FOLLOW_NODES 16
 __global__ __launch_bounds__(WG, 2) void mmp_level_followup_kernel(const LevelArgs a) {
     extern __shared__ double lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int N = a.N, L = a.L, Lp = a.Lp, d = a.depth;
+    const int N = a.N, L = a.L, Lp = a.Lp;
     const int Npad = (N + 3) & ~3;
     const int R32 = CSC_TILE_ROWS + Lp + 4;
     float* slab = reinterpret_cast<float*>(lds_raw);
@@ -1365,7 +1380,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_followup_kernel(const LevelAr
     float* r32 = reinterpret_cast<float*>(r64 + Npad);
     _Float16* r16 = reinterpret_cast<_Float16*>(r32 + ((R32 + 3) & ~3));           // unused here; same carve-up
     NodeLds* sl = reinterpret_cast<NodeLds*>(r16 + R16_COPIES * R16_CS);
-    const int Fd = a.ts.F[d];
+    const int Fd = a.ts.F[a.depth];                                   // the same on every level of the chain
     const size_t total = (size_t)a.S * Fd;
     bool meta_loaded = false;
     // the workgroup's 16 flag bytes in one round trip (the buffer is padded to a multiple of 16 bytes)
@@ -1375,7 +1390,8 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_followup_kernel(const LevelAr
     for (int q = 0; q < FOLLOW_NODES; ++q) {
         const size_t nl = (size_t)blockIdx.x * FOLLOW_NODES + q;
         if (nl >= total) break;
-        if (!(((q < 8 ? f0 : f1) >> (8 * (q & 7))) & 0xff)) continue;    // workgroup-uniform
+        const int fl = (int)(((q < 8 ? f0 : f1) >> (8 * (q & 7))) & 0xff);
+        if (!fl) continue;                                            // workgroup-uniform
         if (!meta_loaded) {
             if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
             if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
@@ -1383,15 +1399,19 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_followup_kernel(const LevelAr
         }
         const size_t s = nl / Fd;
         const int j = (int)(nl - s * Fd);
-        const int nch = children_of(a, j);
-        PROF_INIT(0);
-        const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
-        double rnorm2, first[4];
-        const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2, first);
-        f32x4 acc[MT][NT];
-        corr_tile_gemm(a.bank32t, sl->masks, (L + SLAB - 1) / SLAB, r32 + 64 * wave + lr + lq, slab, acc);
-        select_children<true>(a, sl, r64, simrow, s, j, nch, delta, acc);
-        __syncthreads();
+        for (int d = fl - 1; d < a.Kmax; ++d) {
+            PROF_INIT(0);
+            const double* rin = d == 0 ? a.signals + s * (size_t)N : a.ws[d & 1] + (s * Fd + j) * (size_t)a.NS;
+            double rnorm2, first[4];
+            const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2, first, d);
+            f32x4 acc[MT][NT];
+            corr_tile_gemm(a.bank32t, sl->masks, (L + SLAB - 1) / SLAB, r32 + 64 * wave + lr + lq, slab, acc);
+            select_children<true>(a, sl, r64, simrow, s, j, 1, delta, acc, d, d + 1 < a.Kmax ? a.ws[(d + 1) & 1] : nullptr);
+            // the next level reads what this one wrote (residual row, node tables): make the stores visible to
+            // this workgroup's own later loads (release + acquire at device scope: L1 is not coherent)
+            __threadfence();
+            __syncthreads();
+        }
     }
 }
 
@@ -1541,7 +1561,7 @@ __device__ __forceinline__ float group_finish(const LevelArgs& a, const NodeLds*
 
 struct LeanLds {
     float wgmax[NT / NG][WG / 64];     // sweep 1: maximum of each group per wave
-    int sib_pos[CSC_MAX_CONNECTIONS], sib_atom[CSC_MAX_CONNECTIONS];
+    int sib_pos[1], sib_atom[1];       // (no siblings on the chain levels: group_finish is called with t = 0)
     int s0[NT / NG], s1[NT / NG];      // slab range of each group (outside it the group's blocks are zero padding)
 };
 
@@ -1549,7 +1569,7 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
     extern __shared__ double lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int N = a.N, K = a.K, L = a.L, d = a.depth;
+    const int N = a.N, K = a.K, L = a.L, d0 = a.depth;
     const int nslab = (L + SLAB - 1) / SLAB;
 
     // ---- LDS carve-up: ring [LRING][GBLK] halves | r64 [Npad] | r16 [R16_COPIES][R16_CS] | NodeLds | LeanLds
@@ -1560,26 +1580,21 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
     NodeLds* sl = reinterpret_cast<NodeLds*>(r16 + R16_COPIES * R16_CS);
     LeanLds* ll = reinterpret_cast<LeanLds*>(sl + 1);
 
-    const int Fd = a.ts.F[d];
+    const int Fd = a.ts.F[d0];                                        // = F of every level below (one child per node)
     size_t s;
     int j;
     node_of_block(Fd, s, j);
-    const int nch = children_of(a, j);
-    const int stride = a.ts.pw[d];
     if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
     if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
 
     PROF_INIT(16);
-    const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
+    const double* rin = d0 == 0 ? a.signals + s * (size_t)N : a.ws[d0 & 1] + (s * Fd + j) * (size_t)a.NS;
     double rnorm2, first[4];
-    node_prologue(a, sl, r64, nullptr, Npad, 0, rin, s, j, rnorm2, first);
+    node_prologue(a, sl, r64, nullptr, Npad, 0, rin, s, j, rnorm2, first, d0);
     PROF_MARK(0);
     const float am2 = *a.amax2, am = sqrtf(am2);
-    const bool ok = am2 > 1e-6f && am2 < 1e4f && rnorm2 > 1e-30 && rnorm2 < 1e30;
-    if (tid == 0) a.flags[s * Fd + j] = ok ? 0 : 1;
-    if (!ok) return;                                                 // NaN / Inf / extreme scales: fp32 launch
     const float band = 2.f * ((9.765625e-04f + DELTA_REL + 1e-6f) * am + 2.9802322e-08f * sqrtf((float)L) * (1.f + am));
-    build_r16(r64, N, (float)(1.0 / sqrt(rnorm2)), first, r16);
+    if (tid == 0) a.flags[s * Fd + j] = 0;
     if (tid < NT / NG) {
         // group g's blocks hold a non-zero only in slabs whose first non-zero tile is below 3 (g + 1)
         int lo = nslab, hi = 0;
@@ -1590,20 +1605,44 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
         ll->s0[tid] = min(lo, hi);
         ll->s1[tid] = hi;
     }
-    __syncthreads();
+
+    // The chain cannot go on in fp16 at level d: the node's state goes to its workspace row (level d0's is still
+    // there) and the flag tells the follow-up kernel where to take over.  Workgroup-uniform.
+    auto give_up = [&](int d) {
+        if (d > d0) {
+            double* row = a.ws[d & 1] + (s * Fd + j) * (size_t)a.NS;
+            for (int n = tid; n < N; n += WG) row[n] = r64[n];
+            if (tid < TRI(d)) row[N + tid] = sl->Lf[tid];
+            if (tid < d) row[N + TRI(a.Kmax) + tid] = sl->coefpar[tid];
+        }
+        if (tid == 0) { a.flags[s * Fd + j] = (uint8_t)(d + 1); if (a.stats) atomicAdd(&a.stats[3], 1); }
+    };
 
     f32x4 acc[MT][NG];
     int permv[NG];
     const int prow = 64 * wave + 4 * lq;
-    for (int t = 0; t < nch; ++t) {
+    // ---- the chain: this node, its child, its grandchild ... down to the leaves; the residual, the Cholesky
+    // factor and the coefficients stay in LDS from one level to the next, only the node tables go to HBM
+    for (int d = d0; d < a.Kmax; ++d) {
+        if (d > d0) {                                                 // the window elements build_r16 wants in registers
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = tid + WG * u;
+                first[u] = i < N ? r64[i] : 0.0;
+            }
+        }
+        // NaN / Inf / extreme scales: fp32
+        if (!(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 1e-30 && rnorm2 < 1e30)) { give_up(d); return; }
+        build_r16(r64, N, (float)(1.0 / sqrt(rnorm2)), first, r16);
+        __syncthreads();
         // ---- sweep 1: group maxima -----------------------------------------------------------------------
         // widest atoms first, narrowest last: the last group stays in registers for sweep 2, and the narrow atoms'
         // group is both the one that most often holds the maximum (2 of 3 nodes on config 2) and the cheapest
         for (int g = NT / NG - 1; g >= 0; --g) {
             bool lane_supp;
             gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
-            const float lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, t, permv, acc, lane_supp);
-            const float bv = wave_max(lane_supp ? fmaxf(lmax, 0.f) : lmax);
+            const float lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, 0, permv, acc, lane_supp);
+            const float bv = wave_max(lmax);
             if (lane == 63) ll->wgmax[g][wave] = bv;                  // read behind the barrier below
         }
         if (tid == 0) sl->cand_cnt = 0;
@@ -1615,10 +1654,6 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
         PROF_MARK(1);
         const float m32 = fmaxf(fmaxf(gmax[0], gmax[1]), gmax[2]);
         const float tau = m32 - band;
-        if (0.f >= tau && t > 0) {                 // the value 0 of suppressed entries may compete: fp32 launch
-            if (tid == 0) { a.flags[s * Fd + j] = 1; if (a.stats) atomicAdd(&a.stats[3], 1); }
-            return;
-        }
         // ---- sweep 2: candidates from the groups that reach the band; the last group is still in registers --
         for (int g = 0; g < NT / NG; ++g) {
             if (!(gmax[g] >= tau)) continue;                          // uniform
@@ -1626,7 +1661,7 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
             float lmax;
             if (g != 0) {
                 gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
-                lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, t, permv, acc, lane_supp);
+                lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, 0, permv, acc, lane_supp);
             } else {
                 lmax = -INFINITY;
 #pragma unroll
@@ -1664,17 +1699,13 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
         __syncthreads();
         PROF_MARK(3);
         const int ncand_raw = sl->cand_cnt;
-        if (ncand_raw > CAND_CAP) {                // too many entries in the fp16 band: fp32 launch
-            if (tid == 0) { a.flags[s * Fd + j] = 1; if (a.stats) atomicAdd(&a.stats[3], 1); }
-            return;
-        }
-        rescore_and_choose(a, sl, r64, ncand_raw, false);
+        if (ncand_raw > CAND_CAP) { give_up(d); return; }             // too many entries in the fp16 band: fp32
+        rescore_and_choose(a, sl, r64, ncand_raw, false, d);
         PROF_MARK(5);
-        const int jc = j + t * stride;
-        const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
-        if (tid == 0) { ll->sib_pos[t] = sl->sup_pos[d]; ll->sib_atom[t] = sl->sup_atom[d]; }
-        child_solve_and_write(a, sl, r64, s, jc, cid);
+        const size_t cid = s * a.NN + a.ts.off[d + 1] + j;
+        child_solve_and_write(a, sl, r64, s, j, cid, d, nullptr, true);
         __syncthreads();
+        rnorm2 = sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3];   // the child's ||residual||^2
     }
     PROF_MARK(9);
 }
@@ -1813,7 +1844,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled_kernel(const LevelArgs 
     }
     const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
     double rnorm2, first[4];
-    const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2, first);
+    const float delta = node_prologue(a, sl, r64, r32, Npad, R32, rin, s, j, rnorm2, first, d);
 
     f32x4 acc[MT][NT];
     int permv[NT];
@@ -1897,11 +1928,11 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled_kernel(const LevelArgs 
         if (lane == 0) sl->widx[wave] = bi;
         __syncthreads();
         const int ncand_raw = sl->cand_cnt;
-        rescore_and_choose(a, sl, r64, ncand_raw, zero_band);
+        rescore_and_choose(a, sl, r64, ncand_raw, zero_band, d);
         const int jc = j + t * stride;
         const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
         if (tid == 0) { tl2->sib_pos[t] = sl->sup_pos[d]; tl2->sib_atom[t] = sl->sup_atom[d]; }
-        child_solve_and_write(a, sl, r64, s, jc, cid);
+        child_solve_and_write(a, sl, r64, s, jc, cid, d, a.resid_out, false);
         __syncthreads();
     }
 }
@@ -2251,23 +2282,27 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         const size_t grid = (size_t)S * ts.F[d];
         if (grid > 0x7fffffffULL) FAIL(-11, "batch too large for one launch (%zu workgroups)", grid);
         const int span = timer_begin(st, d);
-        a.flags = nullptr; a.S = S;
+        a.flags = nullptr; a.S = S; a.signals = d_signals; a.ws[0] = ws[0]; a.ws[1] = ws[1];
+        bool chain = false;
         if (tiled) {
             hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
         } else if (lean && grid > 512 && (connections == 1 || ts.pw[d] >= ts.F[d + 1])) {
-            // every node of this level has one child (node j's second child j + pw[d] falls outside F[d + 1]); with
-            // siblings the lean kernel would repeat its sweeps per sibling and the register-resident kernel wins;
-            // 512 nodes or fewer are all resident at once on either kernel
+            // every node of this level has one child (node j's second child j + pw[d] falls outside F[d + 1]), and
+            // so has every node below (pw grows, F stays at `branches`): ONE launch walks each of these chains down
+            // to its leaf, the residual never leaving LDS.  With siblings the lean kernel would repeat its sweeps per
+            // sibling and the register-resident kernel wins; 512 nodes or fewer are all resident at once on either
             a.flags = node_flags;
+            chain = true;
             hipLaunchKernelGGL(mmp_level_lean_kernel, dim3((unsigned)grid), dim3(WG), lean_lds_bytes(N), st, a);
             hipLaunchKernelGGL(mmp_level_followup_kernel, dim3((unsigned)((grid + FOLLOW_NODES - 1) / FOLLOW_NODES)),
-                               dim3(WG), lds, st, a);                // what it flagged: fp32
+                               dim3(WG), lds, st, a);                // the chains it gave up: fp32
         } else {
             hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
         }
         timer_end(st, span);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) FAIL((int)e, "mmp_level_kernel launch failed at level %d: %s", d, hipGetErrorString(e));
+        if (chain) break;                                             // levels d .. max_sparsity - 1 are done
     }
     if (d_rec_mse && d_rec_leaf && d_rec_sel) {
         const size_t tot = (size_t)S * max_sparsity;

@@ -18,7 +18,7 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
 
-KERNELS = ("mmp_level_lean_kernel", "mmp_level_followup_kernel", "mmp_level_kernel")   # levels 1-4, their fp32 follow-up / level 0
+KERNELS = ("mmp_level_lean_kernel", "mmp_level_followup_kernel", "mmp_level_kernel")   # levels 1-4 (one launch), its fp32 follow-up / level 0
 summary = {"kernels": KERNELS,
            "command": "rocprofv3 --pmc <group> -- python3 bench.py --no-cpu-baseline --no-fp32-leg --steps 10 --warmup 2",
            "per_kernel": {}}
@@ -50,14 +50,13 @@ for group in ("pmc_fetch", "pmc_write", "pmc_sq"):
             e["launches"][name] = len(vals)
             e["resources"] = info.get(key, {})
 if n_lean and "FETCH_SIZE" in totals and "WRITE_SIZE" in totals:
-    levels = n_lean // 4 * 5                     # level launches timed by bench.py: 4 lean levels + level 0 per step
+    levels = n_lean * 5                          # per step: level 0 + ONE lean launch that walks levels 1-4
     fetch = totals["FETCH_SIZE"] * 1024 * 2 / levels          # KiB -> B, gfx950 x2 correction
     write = totals["WRITE_SIZE"] * 1024 / levels
     summary["hbm"] = {"fetch_bytes_per_level_corrected": fetch, "write_bytes_per_level": write,
                       "bytes_per_level": fetch + write, "levels": levels}
     json.dump({"bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "profile": tag,
-               "note": "avg over the 5 tree levels of one csc_mmpdf_batch (3200 signals), all level kernels of a level "
-                       "together; FETCH_SIZE KiB x1024 x2 (gfx950 correction), WRITE_SIZE KiB x1024; separate --pmc passes"},
+               "note": "level kernels of one csc_mmpdf_batch (3200 signals) / its 5 tree levels; FETCH_SIZE KiB x1024 x2 (gfx950 correction), WRITE_SIZE KiB x1024; separate --pmc passes"},
               open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 for key, e in summary["per_kernel"].items():
     c = e["counters_avg_per_launch"]
