@@ -1609,13 +1609,15 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
     // The chain cannot go on in fp16 at level d: the node's state goes to its workspace row (level d0's is still
     // there) and the flag tells the follow-up kernel where to take over.  Workgroup-uniform.
     auto give_up = [&](int d) {
+        int tq = threadIdx.x;
+        asm volatile("" : "+v"(tq));                                  // keeps the address parts out of the loop above
         if (d > d0) {
             double* row = a.ws[d & 1] + (s * Fd + j) * (size_t)a.NS;
-            for (int n = tid; n < N; n += WG) row[n] = r64[n];
-            if (tid < TRI(d)) row[N + tid] = sl->Lf[tid];
-            if (tid < d) row[N + TRI(a.Kmax) + tid] = sl->coefpar[tid];
+            for (int n = tq; n < N; n += WG) row[n] = r64[n];
+            if (tq < TRI(d)) row[N + tq] = sl->Lf[tq];
+            if (tq < d) row[N + TRI(a.Kmax) + tq] = sl->coefpar[tq];
         }
-        if (tid == 0) { a.flags[s * Fd + j] = (uint8_t)(d + 1); if (a.stats) atomicAdd(&a.stats[3], 1); }
+        if (tq == 0) { a.flags[s * Fd + j] = (uint8_t)(d + 1); if (a.stats) atomicAdd(&a.stats[3], 1); }
     };
 
     f32x4 acc[MT][NG];
@@ -1625,9 +1627,11 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
     // factor and the coefficients stay in LDS from one level to the next, only the node tables go to HBM
     for (int d = d0; d < a.Kmax; ++d) {
         if (d > d0) {                                                 // the window elements build_r16 wants in registers
+            int tq = threadIdx.x;
+            asm volatile("" : "+v"(tq));
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = tid + WG * u;
+                const int i = tq + WG * u;
                 first[u] = i < N ? r64[i] : 0.0;
             }
         }
