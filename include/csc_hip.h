@@ -101,7 +101,8 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
  *   d_stats     [4] int32 or NULL (must be zeroed by the caller): [0] selections that fell back
  *               to the fp32 arg-max (candidate overflow), [1] re-selected activations (dead Cholesky
  *               columns), [2] number of fp64 re-scored candidates, [3] nodes the fp16 filter could not
- *               settle (multiplied again in fp32)
+ *               settle (multiplied again in fp32; on the single-child levels the rest of the node's chain is
+ *               then done in fp32 too)
  *   workspace   csc_mmpdf_workspace_bytes(...) bytes, 16-byte aligned (hipMalloc's are): two generations of node
  *               residuals + one flag byte per frontier node
  */
