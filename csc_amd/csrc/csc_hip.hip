@@ -2290,11 +2290,12 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         bool chain = false;
         if (tiled) {
             hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
-        } else if (lean && grid > 512 && (connections == 1 || ts.pw[d] >= ts.F[d + 1])) {
+        } else if (lean && (connections == 1 || ts.pw[d] >= ts.F[d + 1])) {
             // every node of this level has one child (node j's second child j + pw[d] falls outside F[d + 1]), and
             // so has every node below (pw grows, F stays at `branches`): ONE launch walks each of these chains down
-            // to its leaf, the residual never leaving LDS.  With siblings the lean kernel would repeat its sweeps per
-            // sibling and the register-resident kernel wins; 512 nodes or fewer are all resident at once on either
+            // to its leaf, the residual never leaving LDS (batches too small to fill the chip gain as well: 170 signals
+            // of config 2 take 187 instead of 231 us).  With siblings the lean kernel would repeat its sweeps per
+            // sibling and the register-resident kernel wins
             a.flags = node_flags;
             chain = true;
             hipLaunchKernelGGL(mmp_level_lean_kernel, dim3((unsigned)grid), dim3(WG), lean_lds_bytes(N), st, a);

@@ -163,7 +163,8 @@ int csc_match_batch(const double* d_bank64, int K, int L, const int32_t* d_true,
  * src/csc/dictionary.py:25-45, logs host wall-clock per method); bench.py uses it to measure the
  * level kernel's launch durations live, on the stream the kernel runs on.  While a timer is
  * attached (per host thread), csc_mmpdf_batch records one span per level launch, tagged with the
- * level, until `capacity` spans are held.  Recording never synchronises; csc_timer_read must be
+ * level (the launch that walks the single-child chains covers several levels and is tagged with the
+ * first of them), until `capacity` spans are held.  Recording never synchronises; csc_timer_read must be
  * called after the stream has been synchronised and returns the number of spans written
  * (elapsed milliseconds + tags), or a negative / hipError_t code. */
 typedef struct csc_timer csc_timer;
