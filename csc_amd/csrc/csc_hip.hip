@@ -1114,7 +1114,9 @@ __device__ __forceinline__ void mask_outside(f32x4 (&acc)[MT][NT], const int (&p
 __device__ __forceinline__ void suppress_similar(const LevelArgs& a, NodeLds* sl, uint32_t* simrow, int p_sel, int k_sel,
                                                  const int (&permv)[NT], f32x4 (&acc)[MT][NT], bool& lane_supp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int W = a.W, W1 = a.W + 1, K = a.K, P = a.P;               // LDS rows padded by one word
+    const int W = a.W, K = a.K, P = a.P;
+    int W1 = a.W + 1;                                                 // LDS rows padded by one word
+    asm volatile("" : "+s"(W1));          // opaque: the nine row offsets are not hoisted out of the sibling loop (spills)
     const uint32_t* g = a.sim_bits + (size_t)k_sel * K * W;
     __syncthreads();
     PROF_MARK(10);
