@@ -28,7 +28,7 @@ for trial in range(trials):
     N = L + P - 1
     c, Kx, B = int(rng.integers(1, 5)), int(rng.integers(2, 8)), int(rng.integers(1, 13))
     Kx = min(Kx, P * K)
-    S = int(rng.integers(520, 700))
+    S = int(rng.integers(20, 700))
     kind = ("noisy", "noiseless", "tiny", "huge", "pairs", "repeat")[trial % 6]
     scale = {"tiny": 1e-6, "huge": 1e5}.get(kind, 1.0)
     sigs = (0.0 if kind == "noiseless" else 0.05) * rng.standard_normal((S, N))
