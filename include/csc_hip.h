@@ -84,8 +84,9 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
  *               within the fp16 rounding bound of the maximum is re-scored in float64; the selections are
  *               the float64 arg-max either way (identical results, the flag exists to check that).
  *               CSC_FLAG_NO_LEAN: tree levels on which every node has one child normally run on a kernel
- *               that takes the fp16 product in three column groups (four nodes per CU instead of two);
- *               the flag keeps them on the register-resident kernel (identical results, same purpose)
+ *               that takes the fp16 product in three column groups (four nodes per CU instead of two) and
+ *               walks each chain of such nodes down to its leaf in one launch; the flag keeps them on the
+ *               register-resident kernel, one launch per level (identical results, same purpose)
  *   d_signals   [S][N] f64
  *   d_node_pos  [S][NN] int32   selected position of the node      (src/csc/mmp.py:74-76)
  *   d_node_atom [S][NN] int32   selected atom index
