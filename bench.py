@@ -106,8 +106,8 @@ def _cpu_warm(_):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)     # a step is 1.4 ms: 100 steps + 30 warm-up steps = 0.2 s,
+    ap.add_argument("--warmup", type=int, default=30)     # enough for the clocks to settle (3 + 20 read 3 % lower)
     ap.add_argument("--per-cell", type=int, default=PER_CELL, help="signals per (snr, sparsity) cell per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-only comparison run (profiling)")
