@@ -7,7 +7,9 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32-leg --steps 10 --warmup 2"
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1 || exit 1
+# the kernel trace runs long enough for the clocks to settle (its averages are compared with bench.py's live spans)
+TRACE="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32-leg --steps 60 --warmup 30"
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $TRACE > $OUT/trace.log 2>&1 || exit 1
 echo "trace done"
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $BENCH > $OUT/pmc_fetch.log 2>&1 || exit 2
 echo "fetch done"
