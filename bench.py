@@ -2,36 +2,44 @@
 """bench.py -- signals/s of batched MMP-DF sparVar (connections 3, branches 3, max sparsity 5,
 dissimilarity 0.8) on MI355X, the metric of BASELINE.json.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 1000 --warmup 100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[1], SURVEY.md section 8d "Config 2"): the 3200-signal sparVar sweep --
 200 constrained synthetic signals per (snr, sparsity) in product([0,5,10,15],[2,3,4,5]), N = 738,
-canonical 143-atom dictionary (L = 492), generator seed = rank.  One step = one pass of the hot path
-(csc_mmpdf_batch: 5 level launches + the per-sparsity reduction) over that batch with the signals
-already resident in HBM; with N > 1 every rank holds its own 3200 signals (weak scaling) and the
-step ends with the ONE gather of the fixed-size sparVar records on rank 0 over RCCL.
+canonical 143-atom dictionary (L = 492), generator seed = rank.  One step = one pass of the hot path over
+that batch with the signals already resident in HBM, through the PRODUCT's own sharded function
+(ZSDictionary.mmpdfSparVarRecords(sharded=True): csc_mmpdf_batch -- level launches + the per-sparsity
+reduction -- then, with N > 1, the ONE gather of the fixed-size device-resident sparVar records on rank 0
+over RCCL); with N > 1 every rank holds its own 3200 signals (weak scaling).
 
 Reported next to `value`:
-  roofline      matrix-core roofline of the level kernels (mmp_level_lean_kernel on the single-child levels 1-4,
-                mmp_level_kernel on level 0; one timed span per tree level), launch durations measured
-                live with HIP events on the launch stream (csc_timer in include/csc_hip.h).  A node's
-                correlations are taken on the fp16 matrix cores as a filter and the entries in its rounding
-                band are re-scored in float64: algorithmic flops per signal = n_sel * 2*P*K*L, n_sel = 13
-                (dense semantics of the reference, the atoms' zero padding NOT discounted), against the dense
-                fp16 MFMA peak; the same figure against the fp32 MFMA peak of BASELINE.json's metric is
-                given beside it.
+  roofline      matrix-core roofline of the level kernels, launch durations measured live with HIP events on
+                the launch stream (csc_timer in include/csc_hip.h).  A node's correlations are taken on the
+                fp16 matrix cores as a filter and the entries in its rounding band are re-scored in float64:
+                algorithmic flops per signal = n_sel * 2*P*K*L, n_sel = 13 (dense semantics of the reference,
+                the atoms' zero padding NOT discounted), against the dense fp16 MFMA peak; `issued_frac` is
+                the fraction of that peak really issued (all-zero bank blocks are skipped).
   fp32_path     the same batch with CSC_FLAG_FP32_ONLY (every node correlated on v_mfma_f32_16x16x4_f32, the
                 path BASELINE.json's north star describes), against the fp32 MFMA peak; identical records.
+  config5       BASELINE.json configs[4]: 125 000 signals per rank (the config-2 clean signals repeated with
+                fresh noise, seed = base + rank), solved in chunks, ONE gather at the end.
   cpu_baseline  the oracle's reference-faithful mode (oaconvolve over all atoms + lsqr defaults + one
                 fresh tree per sparsity = the reference's cost structure; kind "port" because the
                 reference's files cannot travel to the GPU box) on a bounded sample, rank 0, N = 1 only.
 """
+import os
+
+# CPU-baseline workers (spawned below with this variable set) must size their BLAS / FFT pools BEFORE numpy
+# loads: one thread per worker process.
+if os.environ.get("CSC_BENCH_CPU_WORKER") == "1":
+    for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ[_v] = "1"
+
 import argparse
 import itertools
 import json
-import os
 import sys
 import time
 
@@ -47,6 +55,8 @@ SNR_LEVELS, SPARSITY_LEVELS = [0, 5, 10, 15], [2, 3, 4, 5]
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 FP16_MFMA_PEAK_TFLOPS = 2500.0     # same guide, "Peak BF16/FP16 MFMA": ~2.5 PF dense
 CPU_SAMPLE = [i * PER_CELL + 7 for i in (0, 3, 5, 6, 9, 10, 12, 15)]   # one signal in 8 of the 16 cells
+CONFIG5_PER_RANK = 125000
+TRAFFIC_PROFILE = os.path.join("profiles", "r02_hbm_traffic.json")
 
 
 def canonical_dictionary():
@@ -54,14 +64,24 @@ def canonical_dictionary():
     return csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.005), np.arange(0.010, 0.036, 0.002), [1])
 
 
-def make_signals(dic, seed, per_cell=PER_CELL):
-    """Config-2 batch with the product's own generator (reference src/csc/dictionary.py:271-365)."""
+def make_signals(dic, seed, per_cell=PER_CELL, with_parts=False):
+    """Config-2 batch with the product's own generator (reference src/csc/dictionary.py:271-365).
+    ``with_parts``: also the clean signals and the noise sigma of each (for the config-5 leg)."""
     np.random.seed(seed)
-    out = []
+    out, clean, sigma = [], [], []
     for snr, sp in itertools.product(SNR_LEVELS, SPARSITY_LEVELS):
         for _ in range(per_cell):
-            s, _ = dic.generateConstrainedTestSignal(SIGNAL_LENGTH, sp, snr, 10, 0.75)
+            s, infos = dic.generateConstrainedTestSignal(SIGNAL_LENGTH, sp, snr, 10, 0.75)
             out.append(s)
+            if with_parts:
+                c = np.zeros(SIGNAL_LENGTH)
+                for a in infos:
+                    c += dic.atoms[dic._atom_index(a)].getAtomInSignal(SIGNAL_LENGTH, a["x"])
+                clean.append(c)
+                active = c[np.abs(c) > 1e-3]
+                sigma.append(np.sqrt(np.var(active) / (10 ** (snr / 10))))   # reference :318-322
+    if with_parts:
+        return np.array(out), np.array(clean), np.array(sigma)
     return np.array(out)
 
 
@@ -75,42 +95,61 @@ def _cpu_job(sig):
     return time.time() - t0
 
 
+def _cpu_warm(_):
+    from oracle import csc_oracle as O
+    _cpu_job.dic = O.canonical_dictionary()
+    return int(os.environ.get("OMP_NUM_THREADS", "-1"))
+
+
 def cpu_baseline(signals):
-    """Reference-faithful CPU path on len(CPU_SAMPLE) signals, one process per signal."""
+    """Reference-faithful CPU path on len(CPU_SAMPLE) signals, one single-threaded process per signal; next to
+    it the same on ONE process alone (2 signals), so that contention between the workers shows."""
     import multiprocessing as mp
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(len(CPU_SAMPLE), avail, int(os.environ.get("OMP_NUM_THREADS", "16") or 16)))
+    cores = max(1, min(len(CPU_SAMPLE), avail))
     sample = [signals[i] for i in CPU_SAMPLE]
-    ctx = mp.get_context("spawn")
-    with ctx.Pool(cores) as pool:
-        pool.map(_cpu_warm, range(cores))                    # imports + dictionary build, untimed
-        t0 = time.time()
-        per = pool.map(_cpu_job, sample, chunksize=1)
-        wall = time.time() - t0
+    saved = {v: os.environ.get(v) for v in ("CSC_BENCH_CPU_WORKER", "OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS",
+                                            "MKL_NUM_THREADS")}
+    # the spawned workers inherit these and re-import this module: thread pools are sized before numpy loads
+    os.environ.update(CSC_BENCH_CPU_WORKER="1", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    try:
+        ctx = mp.get_context("spawn")
+        with ctx.Pool(1) as pool:
+            threads = pool.map(_cpu_warm, [0])
+            solo = pool.map(_cpu_job, sample[:2], chunksize=1)
+        with ctx.Pool(cores) as pool:
+            pool.map(_cpu_warm, range(cores))                    # imports + dictionary build, untimed
+            t0 = time.time()
+            per = pool.map(_cpu_job, sample, chunksize=1)
+            wall = time.time() - t0
+    finally:
+        for v, x in saved.items():
+            if x is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = x
     return {"value": len(sample) / wall, "unit": "signals/s", "cores": cores, "kind": "port",
             "sample": f"{len(sample)} of the {len(signals)} signals (indices {CPU_SAMPLE}), oracle mode "
-                      f"'faithful' (oaconvolve + lsqr, one tree per sparsity = 50 nodes/signal), "
-                      f"{sum(per):.1f} CPU-s, {np.mean(per):.2f} s/signal/core"}
-
-
-def _cpu_warm(_):
-    os.environ["OMP_NUM_THREADS"] = "1"
-    from oracle import csc_oracle as O
-    _cpu_job.dic = O.canonical_dictionary()
-    return 0
+                      f"'faithful' (oaconvolve + lsqr, one tree per sparsity = 50 nodes/signal), one "
+                      f"single-threaded process per signal (OMP_NUM_THREADS={threads[0]} in the workers), "
+                      f"{sum(per):.1f} CPU-s, {np.mean(per):.2f} s/signal/core",
+            "one_process": {"s_per_signal": float(np.mean(solo)), "signals": len(solo),
+                            "note": "the same job on one process with the other cores idle"},
+            "host_cores_available": avail}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)     # a step is 1.4 ms: 100 steps + 30 warm-up steps = 0.2 s,
-    ap.add_argument("--warmup", type=int, default=30)     # enough for the clocks to settle (3 + 20 read 3 % lower)
+    ap.add_argument("--steps", type=int, default=1000)    # a step is ~1.3 ms: the timed region lasts > 1 s, clocks
+    ap.add_argument("--warmup", type=int, default=100)    # settled (100 steps)
     ap.add_argument("--per-cell", type=int, default=PER_CELL, help="signals per (snr, sparsity) cell per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-only comparison run (profiling)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the 125 000-signals-per-rank leg")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,7 +159,7 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
 
     dic = canonical_dictionary()
-    signals = make_signals(dic, seed=rank, per_cell=a.per_cell)
+    signals, clean, sigma = make_signals(dic, seed=rank, per_cell=a.per_cell, with_parts=True)
     S, N = signals.shape
 
     cpu = None
@@ -130,45 +169,47 @@ def main():
     import torch
     import torch.distributed as dist
     from csc_amd import _lib
-    torch.cuda.set_device(local_rank)
+    from csc_amd import distributed as D
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run (also with 1 rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
+        torch.cuda.set_device(local_rank)                 # for init_process_group(device_id=...); csc_amd picks
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # cuda:LOCAL_RANK by itself
     bank = dic.device_bank()
+    assert bank.device == dev == D.local_device(), (bank.device, dev)
     K, L = bank.K, bank.L
     P = N - L + 1
     sizes, NN = _lib.tree_shape(MAX_SPARSITY, CONNECTIONS, BRANCHES)
     n_sel = 1 + sum(sizes[:-1])
     flops_per_signal = n_sel * 2.0 * P * K * L
+    rec_bytes = MAX_SPARSITY * (16 + 8 * MAX_SPARSITY)
+
+    def solve(sig, **kw):
+        """The product's sharded sparVar call: device signals in, device records out (rank 0: all ranks')."""
+        return dic.mmpdfSparVarRecords(sig, CONNECTIONS, DISSIMILARITY, BRANCHES, MAX_SPARSITY, sharded=True,
+                                       presharded=True, **kw)
 
     # PCIe-inclusive pass (host signals in, host records out) -- reported, never `value`
     t0 = time.time()
     d_sig = torch.from_numpy(signals).to(dev)
-    out = bank.mmpdf_launch(d_sig, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY, want_coef=False)
-    host_rec = out["rec_buf"].cpu()
-    torch.cuda.synchronize(dev)
+    host_rec = bank.mmpdf_records(d_sig, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY)[0].cpu()
     first_call_s = time.time() - t0
     t0 = time.time()
     d_sig2 = torch.from_numpy(signals).to(dev)
-    bank.mmpdf_launch(d_sig2, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY, want_coef=False, out=out)
-    host_rec = out["rec_buf"].cpu()
-    torch.cuda.synchronize(dev)
+    host_rec = bank.mmpdf_records(d_sig2, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY)[0].cpu()
     pcie_s = time.time() - t0
     del d_sig2
 
-    gathered = [torch.empty_like(out["rec_buf"]) for _ in range(world)] if (use_dist and rank == 0) else None
+    shard_sizes = [S] * world
+    recv = [torch.empty((S, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(world)] \
+        if (use_dist and rank == 0) else None
+    step_kw = dict(shard_sizes=shard_sizes, recv=recv)
 
-    def step():
-        bank.mmpdf_launch(d_sig, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY, want_coef=False, out=out)
-        if use_dist:
-            dist.gather(out["rec_buf"], gathered, dst=0)      # the ONE collective of the path: sparVar records
-
+    rows = None
     for _ in range(a.warmup):
-        step()
+        rows = solve(d_sig, **step_kw)
     timer = _lib.LevelTimer(capacity=a.steps * MAX_SPARSITY)
     torch.cuda.synchronize(dev)
     if use_dist:
@@ -177,7 +218,7 @@ def main():
     t0 = time.perf_counter()
     with timer:
         for _ in range(a.steps):
-            step()
+            rows = solve(d_sig, **step_kw)
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
@@ -185,12 +226,16 @@ def main():
     elapsed = time.perf_counter() - t0
     spans = timer.read()
     timer.close()
-    stats = out["stats"].cpu().numpy().tolist()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    if rank == 0:      # rank 0's own records come first in the gathered rows
+        assert rows is not None and rows.shape == (world * S, rec_bytes)
+        assert torch.equal(rows[:S].cpu(), host_rec), "gathered records differ from the single-call records"
+    own, stats_t = bank.mmpdf_records(d_sig, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY)
+    stats = stats_t.cpu().numpy().tolist()
 
     # the same batch correlated in fp32 only (CSC_FLAG_FP32_ONLY): the "% of fp32 MFMA peak" leg of
     # BASELINE.json's metric; outside the timed region, no collective
@@ -199,7 +244,7 @@ def main():
         bank.fp32_only = True
         out_m = bank.mmpdf_launch(d_sig, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY, want_coef=False)
         torch.cuda.synchronize(dev)
-        msteps = max(2, min(5, a.steps))
+        msteps = max(2, min(20, a.steps))
         timer_m = _lib.LevelTimer(capacity=msteps * MAX_SPARSITY)
         t0 = time.perf_counter()
         with timer_m:
@@ -210,7 +255,45 @@ def main():
         spans_m = timer_m.read()
         timer_m.close()
         bank.fp32_only = False
-        same = bool(torch.equal(out_m["rec_buf"], out["rec_buf"]))
+        same = bool(torch.equal(out_m["rec_buf"], own))
+
+    # ---- config 5: 125 000 signals per rank, chunked solve, ONE gather at the end ---------------------------
+    config5 = None
+    if not a.no_config5:
+        g = torch.Generator(device=dev)
+        g.manual_seed(1000 + rank)
+        reps = (CONFIG5_PER_RANK + S - 1) // S
+        d_clean = torch.from_numpy(clean).to(dev).repeat(reps, 1)[:CONFIG5_PER_RANK]
+        d_sigma = torch.from_numpy(sigma).to(dev).repeat(reps)[:CONFIG5_PER_RANK]
+        big = d_clean + d_sigma[:, None] * torch.randn(d_clean.shape, generator=g, dtype=torch.float64, device=dev)
+        del d_clean
+        sizes5 = [CONFIG5_PER_RANK] * world
+        solve(big, shard_sizes=sizes5)                     # untimed: allocator warm-up
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        nrep = 3
+        for _ in range(nrep):
+            rows5 = solve(big, shard_sizes=sizes5)
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t5 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            assert rows5.shape == (world * CONFIG5_PER_RANK, rec_bytes)
+            config5 = {"value": world * CONFIG5_PER_RANK * nrep / float(t5.item()), "unit": "signals/s",
+                       "signals_per_rank": CONFIG5_PER_RANK, "total_signals": world * CONFIG5_PER_RANK,
+                       "ms_per_pass": float(t5.item()) / nrep * 1e3, "passes": nrep,
+                       "chunk": dic.PIPELINE_CHUNK, "gathers_per_pass": 1 if use_dist else 0,
+                       "note": "config-2 clean signals repeated with fresh Gaussian noise at each signal's SNR "
+                               "(seed 1000 + rank), resident in HBM; mmpdfSparVarRecords(sharded=True): chunked "
+                               "solve, then one gather of the %d-byte records" % rec_bytes}
+        del big
 
     if rank == 0:
         ms_step = elapsed / a.steps * 1e3
@@ -257,22 +340,26 @@ def main():
                 "note": "same batch with CSC_FLAG_FP32_ONLY: every node correlates its residual on "
                         "v_mfma_f32_16x16x4_f32 (DeviceBank.fp32_only = True); identical records: %s" % same,
                 "value": S * msteps / fp32_elapsed, "unit": "signals/s",
-                "roofline": {"bound": "mfma", "achieved": achieved_m, "peak": FP32_MFMA_PEAK_TFLOPS,
-                             "unit": "TFLOP/s", "frac": achieved_m / FP32_MFMA_PEAK_TFLOPS,
+                "roofline": {"bound": "mfma", "achieved": issued, "peak": FP32_MFMA_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": issued / FP32_MFMA_PEAK_TFLOPS,
+                             "dense_equivalent_tflops": achieved_m,
+                             "dense_equivalent_over_peak": achieved_m / FP32_MFMA_PEAK_TFLOPS,
                              "launch_ms_avg": launch_ms_m,
                              "launch_ms_by_level": {str(d): float(np.mean([ms for lv, ms in spans_m if lv == d]))
                                                     for d in sorted({lv for lv, _ in spans_m})},
-                             "flops_per_launch": flops_per_launch,
-                             "mfma_issued": {"tflops": issued, "frac_of_peak": issued / FP32_MFMA_PEAK_TFLOPS,
-                                             "blocks_per_node": blocks, "of_dense_blocks": nslab * 9,
-                                             "note": "`achieved` counts the reference's dense 2*P*K*L flops per "
-                                                     "node; bank blocks that are all zero padding are skipped, "
-                                                     "so fewer flops are issued"}}}
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+                             "flops_per_launch_dense": flops_per_launch,
+                             "blocks_per_node": blocks, "of_dense_blocks": nslab * 9,
+                             "note": "`achieved` / `frac` count the fp32 MFMA flops really issued (bank blocks that "
+                                     "are all zero padding are skipped); `dense_equivalent_*` counts the "
+                                     "reference's dense 2*P*K*L flops per node over the same time and can "
+                                     "exceed 1"}}
+        traffic, traffic_src = None, None
+        tf = os.path.join(ROOT, TRAFFIC_PROFILE)
         if os.path.exists(tf):
             with open(tf) as f:
                 traffic = json.load(f).get("bytes_per_launch")
+            traffic_src = TRAFFIC_PROFILE + " (static: rocprofv3 PMC passes over this command, taken when the " \
+                                            "profile was committed; not measured by this run)"
         line = {
             "metric": "signals/sec for MMP-DF (3 branches, sparsity<=5)", "value": value, "unit": "signals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
@@ -282,39 +369,39 @@ def main():
                                    "constrained), MMP-DF connections 3 / branches 3 / max sparsity 5 / "
                                    "dissimilarity 0.8, per GPU",
                        "signals_per_gpu": S, "signal_length": N, "atoms": K, "atom_length": L,
-                       "nodes_per_signal": NN, "parallelism": f"signals sharded over {world} rank(s), "
-                                                              "one RCCL gather of the sparVar records per step"
-                                                              if world > 1 else "single GPU"},
+                       "nodes_per_signal": NN,
+                       "parallelism": (f"signals sharded over {world} ranks (one per GPU), no traffic during the "
+                                       f"solve, one RCCL gather of the {rec_bytes}-byte device-resident sparVar "
+                                       "records per step (ZSDictionary.mmpdfSparVarRecords(sharded=True))")
+                       if world > 1 else "single GPU (ZSDictionary.mmpdfSparVarRecords)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP16_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "frac": achieved / FP16_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "issued_tflops": issued16, "issued_frac": issued16 / FP16_MFMA_PEAK_TFLOPS,
                          "kernel": "mmp_level_lean_kernel (levels 1-4, one launch) + mmp_level_kernel (level 0)",
                          "launch_ms_avg": launch_ms, "launch_ms_by_level": per_level,
                          "flops_per_launch": flops_per_launch, "flops_per_signal": flops_per_signal,
                          "launches_timed": len(spans),
                          "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "mfma_issued": {"tflops": issued16, "frac_of_peak": issued16 / FP16_MFMA_PEAK_TFLOPS,
-                                         "blocks_per_node": blocks16, "of_dense_blocks": nslab * 9,
-                                         "note": "v_mfma_f32_16x16x32_f16 flops issued by the filter when no column "
-                                                 "group is multiplied twice (lower bound; runs of all-padding "
-                                                 "column tiles are skipped)"},
+                         "blocks_per_node": blocks16, "of_dense_blocks": nslab * 9,
                          "note": "correlations on the fp16 matrix cores as a filter (arithmetic dtype f16, fp32 "
                                  "accumulation), selection decided by a float64 re-score of the entries in the "
-                                 "fp16 rounding band; `achieved` counts the reference's dense 2*P*K*L flops per "
-                                 "selecting node; `traffic` is HBM bytes per launch (rocprofv3 PMC, "
-                                 "profiles/hbm_traffic.json)"},
+                                 "fp16 rounding band; `achieved` / `frac` count the reference's dense 2*P*K*L flops "
+                                 "per selecting node (algorithmic flops per launch / measured launch time), "
+                                 "`issued_*` the v_mfma_f32_16x16x32_f16 flops issued when no column group is "
+                                 "multiplied twice (lower bound; all-padding column tiles are skipped); the answer "
+                                 "to BASELINE.json's '% fp32 MFMA peak' is fp32_path"},
             "fp32_path": fp32_path,
+            "config5": config5,
             "cpu_baseline": cpu,
             "pcie_inclusive": {"value": S / pcie_s, "unit": "signals/s",
                                "note": "one call: host f64 signals -> HBM, solve, sparVar records -> host",
                                "first_call_s": first_call_s},
             "fp32_argmax_fallbacks": stats[0], "duplicate_columns": stats[1],
-            "rescored_candidates_per_selection": stats[2] / max(1, a.steps + a.warmup + 2) / (S * NN),
-            "nodes_repeated_in_fp32": stats[3] // max(1, a.steps + a.warmup + 2),
+            "rescored_candidates_per_selection": stats[2] / (S * NN),
+            "nodes_repeated_in_fp32": stats[3],
         }
         print(json.dumps(line), flush=True)
     if use_dist:
-        if rank == 0:      # the gathered buffers hold every rank's records, rank 0's own first
-            assert torch.equal(gathered[0], out["rec_buf"])
         dist.barrier()
         dist.destroy_process_group()
 

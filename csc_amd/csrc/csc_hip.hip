@@ -1717,6 +1717,97 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
 }
 
 // ------------------------------------------------------------------------------------------------
+// test aid: the fp16 filter product itself (what the level kernels only ever hold in registers)
+// ------------------------------------------------------------------------------------------------
+// out[b][p][k] = the fp16 matrix-core product of signal b scaled to unit norm with atom k at shift p, in units of
+// ||signal||, taken by the very loops the level kernels use: variant 0 = corr_tile_gemm16 (mmp_level_kernel),
+// variant 1 = gemm16_group over the three column groups (mmp_level_lean_kernel).  eps[b] = the rounding bound the
+// kernels assume for an entry (half their candidate band); norm[b] = ||signal||.  tests/test_gpu_filter_bound.py
+// checks |out - float64| <= eps on golden residuals and adversarial operands.
+__global__ __launch_bounds__(WG, 2) void filter_product_kernel(const _Float16* __restrict__ bank16,
+                                                               const int32_t* __restrict__ meta, const float* amax2,
+                                                               int K, int L, const double* __restrict__ signals, int N,
+                                                               int P, int variant, float* __restrict__ out,
+                                                               float* __restrict__ eps, double* __restrict__ norm) {
+    extern __shared__ double lds_raw[];
+    __shared__ uint32_t masks[MAX_SLABS];
+    __shared__ int perm[CSC_TILE_COLS];
+    __shared__ double wsum[WG / 64];
+    __shared__ int gs0[NT / NG], gs1[NT / NG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int nslab = (L + SLAB - 1) / SLAB;
+    const int Npad = (N + 3) & ~3;
+    _Float16* ring = reinterpret_cast<_Float16*>(lds_raw);            // [RING16][SLABF] halves (>= [LRING][GBLK])
+    double* r64 = lds_raw + (RING16 * SLABF) / 4;
+    _Float16* r16 = reinterpret_cast<_Float16*>(r64 + Npad);
+    const size_t b = blockIdx.x;
+    if (tid < MAX_SLABS) masks[tid] = (uint32_t)meta[CSC_TILE_COLS + tid];
+    if (tid < CSC_TILE_COLS) perm[tid] = meta[tid];
+    double first[4], ss = 0.0;
+    for (int i0 = 0; i0 < Npad; i0 += 4 * WG) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + tid + WG * u;
+            const double v = i < N ? signals[b * N + i] : 0.0;
+            if (i < Npad) r64[i] = v;
+            ss = fma(v, v, ss);
+            if (i0 == 0) first[u] = v;
+        }
+    }
+    ss = wave_sum(ss);
+    if (lane == 63) wsum[wave] = ss;
+    __syncthreads();
+    const double rnorm2 = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (tid < NT / NG) {
+        int lo = nslab, hi = 0;
+        for (int q = 0; q < nslab; ++q) {
+            const uint32_t m = masks[q];
+            if (m && (int)__builtin_ctz(m) < NG * (tid + 1)) { lo = min(lo, q); hi = q + 1; }
+        }
+        gs0[tid] = min(lo, hi);
+        gs1[tid] = hi;
+    }
+    const float am = sqrtf(*amax2);
+    if (tid == 0) {
+        eps[b] = (9.765625e-04f + DELTA_REL + 1e-6f) * am + 2.9802322e-08f * sqrtf((float)L) * (1.f + am);
+        norm[b] = sqrt(rnorm2);
+    }
+    build_r16(r64, N, (float)(1.0 / sqrt(rnorm2)), first, r16);
+    __syncthreads();
+    const int prow = 64 * wave + 4 * lq;
+    if (variant == 0) {
+        f32x4 acc[MT][NT];
+        WAIT_VM(0);
+        gemm16_prefetch(bank16, nslab, ring);
+        corr_tile_gemm16(bank16, masks, nslab, r16, ring, acc);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int p = prow + 16 * mi + rg, k = perm[16 * ni + lr];
+                    if (p < P && k >= 0) out[(b * P + p) * K + k] = acc[mi][ni][rg];
+                }
+    } else {
+        for (int g = NT / NG - 1; g >= 0; --g) {
+            f32x4 acc[MT][NG];
+            gemm16_group(bank16, g, gs0[g], gs1[g], r16, ring, acc);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < NG; ++nj)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int p = prow + 16 * mi + rg, k = perm[16 * (NG * g + nj) + lr];
+                        if (p < P && k >= 0) out[(b * P + p) * K + k] = acc[mi][nj][rg];
+                    }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // the tiled level kernel: dictionaries with more than 144 atoms and/or more than 256 positions
 // ------------------------------------------------------------------------------------------------
 // Same node semantics as mmp_level_kernel, but the (P x K) correlation matrix no longer fits one
@@ -1909,8 +2000,16 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled_kernel(const LevelArgs 
                         const int idx = rowK + (16 * (r >> 2) + (r & 3)) * K + sl->perm[16 * ni + lr];
                         const int slot = atomicAdd(&sl->cand_cnt, 1);
                         if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
-                        bi = min(bi, idx);
                     }
+                }
+                if (lmax == gmax) {                                   // overflow fallback: entries equal to the maximum
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                            for (int ni = 0; ni < NT; ++ni)
+                                if (acc[mi][ni][rg] == gmax) bi = min(bi, rowK + (16 * mi + rg) * K + permv[ni]);
                 }
             }
             if (zero_band) {
@@ -1922,6 +2021,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled_kernel(const LevelArgs 
                         for (int ni = 0; ni < NT; ++ni)
                             if (is_supp(acc[mi][ni][rg]))
                                 first_supp = min(first_supp, rowK + (16 * mi + rg) * K + permv[ni]);
+                if (gmax == 0.f) bi = min(bi, first_supp);            // the value 0 of suppressed entries is the maximum
             }
             __syncthreads();                                          // perm / masks are rewritten by the next unit
         }
@@ -1929,7 +2029,8 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled_kernel(const LevelArgs 
             first_supp = wave_min(first_supp);
             if (lane == 0) sl->wsupp[wave] = first_supp;
         }
-        // overflow fallback (never seen on real data): lowest index among the band entries
+        // overflow fallback (never seen on real data): lowest index among the entries equal to the fp32 maximum,
+        // as in mmp_level_kernel (suppressed entries count with their value 0)
         bi = wave_min(bi);
         if (lane == 0) sl->widx[wave] = bi;
         __syncthreads();
@@ -2015,19 +2116,32 @@ __global__ __launch_bounds__(64) void match_kernel(const double* __restrict__ ba
 __global__ void reduce_kernel(int S, int Kmax, int NN, TreeShape ts, const int32_t* __restrict__ node_pos,
                               const int32_t* __restrict__ node_atom, const double* __restrict__ node_mse,
                               double* __restrict__ rec_mse, int32_t* __restrict__ rec_leaf,
-                              int32_t* __restrict__ rec_sel) {
+                              int32_t* __restrict__ rec_sel, int aos) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)S * Kmax) return;
     const size_t s = i / Kmax;
     const int k = (int)(i % Kmax) + 1;
+    if (aos) {
+        // CSC_FLAG_RECORDS_AOS: one contiguous record per signal, K f64 mse | K x 2 i32 leaf | K x K x 2 i32 (pos, atom);
+        // rec_mse is the base of the [S][(16 + 8 K) K] byte buffer (rec_leaf / rec_sel are ignored)
+        char* rec = reinterpret_cast<char*>(rec_mse) + s * (size_t)(16 + 8 * Kmax) * Kmax;
+        const size_t back = s * Kmax;                                 // the dense indexing below is per batch
+        rec_mse = reinterpret_cast<double*>(rec) - back;
+        rec_leaf = reinterpret_cast<int32_t*>(rec + 8 * Kmax) - 2 * back;
+        rec_sel = reinterpret_cast<int32_t*>(rec + 16 * Kmax) - back * Kmax * 2;
+    }
     const double* mse = node_mse + s * NN + ts.off[k];
     double m = INFINITY;
-    int last = 0, first = 0;
+    int last = 0, first = 0, first_nan = -1;
     for (int j = 0; j < ts.F[k]; ++j) {
         const double v = mse[j];
+        if (v != v && first_nan < 0) first_nan = j;
         if (v <= m) { if (v < m) first = j; m = v; last = j; }
     }
-    // NaN-only levels keep leaf 0 (np.argmin returns the first NaN; '<=' never fires)
+    // NaN rule.  First minimum: np.argmin (src/csc/mmp.py:464) returns the first NaN when there is one.  Last
+    // minimum: the reference's '<=' loop (:583-587) never fires on a NaN, so NaNs are skipped; on a NaN-only level
+    // the reference raises (argmin_leaf stays None) -- here that level reports leaf 0 with its NaN MSE.
+    if (first_nan >= 0) first = first_nan;
     rec_mse[i] = node_mse[s * NN + ts.off[k] + last];
     rec_leaf[2 * i] = last;
     rec_leaf[2 * i + 1] = first;
@@ -2311,10 +2425,11 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         if (e != hipSuccess) FAIL((int)e, "mmp_level_kernel launch failed at level %d: %s", d, hipGetErrorString(e));
         if (chain) break;                                             // levels d .. max_sparsity - 1 are done
     }
-    if (d_rec_mse && d_rec_leaf && d_rec_sel) {
+    if (d_rec_mse && ((d_rec_leaf && d_rec_sel) || (flags & CSC_FLAG_RECORDS_AOS))) {
         const size_t tot = (size_t)S * max_sparsity;
         hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, S, max_sparsity,
-                           NN, ts, d_node_pos, d_node_atom, d_node_mse, d_rec_mse, d_rec_leaf, d_rec_sel);
+                           NN, ts, d_node_pos, d_node_atom, d_node_mse, d_rec_mse, d_rec_leaf, d_rec_sel,
+                           (flags & CSC_FLAG_RECORDS_AOS) ? 1 : 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) FAIL((int)e, "reduce_kernel launch failed: %s", hipGetErrorString(e));
     }
@@ -2331,6 +2446,26 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
     return run_levels(0, d_bank32t, d_bank64, d_sim_bits, K, L, d_signals, S, N, max_sparsity, connections,
                       branches, flags, d_workspace, workspace_bytes, d_node_pos, d_node_atom, d_node_mse, d_node_coef,
                       d_rec_mse, d_rec_leaf, d_rec_sel, d_stats, stream);
+}
+
+int csc_filter_product(const float* d_bank32t, int K, int L, const double* d_signals, int B, int N,
+                       int variant, float* d_prod, float* d_eps, double* d_norm, void* stream) {
+    const int P = N - L + 1;
+    if (!d_bank32t || !d_signals || !d_prod || !d_eps || !d_norm || K <= 0 || L <= 0 || B < 0)
+        FAIL(-1, "csc_filter_product: bad arguments");
+    if (P <= 0) FAIL(-6, "signal length %d shorter than atom length %d", N, L);
+    if (K > CSC_TILE_COLS || P > CSC_TILE_ROWS || n_slabs(L) * SLAB > 512 || N > 4 * WG)
+        FAIL(-9, "csc_filter_product: the fp16 filter covers K <= %d, P <= %d, L <= 512, N <= %d", CSC_TILE_COLS,
+             CSC_TILE_ROWS, 4 * WG);
+    if (variant != 0 && variant != 1) FAIL(-1, "csc_filter_product: variant must be 0 or 1");
+    if (B == 0) return 0;
+    const size_t lds = (size_t)RING16 * SLABF * 2 + (size_t)ceil4(N) * 8 + R16_COPIES * R16_CS * 2;
+    clear_stale_error();
+    hipFuncSetAttribute((const void*)filter_product_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(filter_product_kernel, dim3(B), dim3(WG), lds, (hipStream_t)stream, bank_tiles16(d_bank32t, K, L),
+                       bank_meta(d_bank32t, K, L), bank_amax2(d_bank32t, K, L), K, L, d_signals, N, P, variant, d_prod,
+                       d_eps, d_norm);
+    return launch_status("filter_product_kernel");
 }
 
 int csc_mp_batch(const float* d_bank32t, const double* d_bank64, int K, int L, const double* d_signals,

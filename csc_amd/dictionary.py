@@ -113,12 +113,14 @@ class CSCDictionary:
     # device residency
     # ------------------------------------------------------------------------------------------
     def device_bank(self):
-        """The HBM-resident atom bank (built on first use on the current GPU)."""
+        """The HBM-resident atom bank (built on first use on this process's GPU: the current device, or
+        cuda:LOCAL_RANK under an initialised multi-rank process group -- csc_amd.distributed.local_device)."""
         import torch
+        from . import distributed as D
         from .engine import DeviceBank
-        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
-        if self._device_bank is None or self._device_bank.device.index != dev:
-            self._device_bank = DeviceBank(self.getLocalDictionary())
+        dev = D.local_device() if torch.cuda.is_available() else None
+        if self._device_bank is None or self._device_bank.device != dev:
+            self._device_bank = DeviceBank(self.getLocalDictionary(), device=dev)
         return self._device_bank
 
     def _info(self, pos, atom_idx) -> dict:
@@ -332,41 +334,79 @@ class CSCDictionary:
     # ------------------------------------------------------------------------------------------
     # batched engine front-ends
     # ------------------------------------------------------------------------------------------
-    def _batch(self, signals, max_sparsity, connections, branches, dissimilarity, want_coef=False,
-               sharded=False):
-        """signals [S, N] -> (BatchResult, amortised seconds per signal).
+    def _records(self, signals, max_sparsity, connections, branches, dissimilarity, want_coef=False,
+                 fields="rec", sharded=False, presharded=False, shard_sizes=None, recv=None):
+        """The device-level core of every batched front-end: signals [S, N] (host array or device tensor) ->
+        ([S, width] uint8 per-signal records ON THE DEVICE, stats tensor), layout BatchResult.field_specs.
 
-        ``sharded=True`` (the pipelines): under torch.distributed every rank solves its contiguous
-        slice of the batch on its own GPU and the fixed-size records are gathered ONCE on rank 0;
-        the other ranks get (None, dt).  Replaces joblib.Parallel (reference :1147)."""
+        ``sharded=True`` (the pipelines): under torch.distributed every rank solves its contiguous slice of
+        the batch on its own GPU (chunks of PIPELINE_CHUNK signals) and the records are gathered ONCE,
+        device to device, on rank 0; the other ranks get (None, stats).  Replaces joblib.Parallel
+        (reference :1147).  ``presharded=True``: ``signals`` already is this rank's shard (``shard_sizes``:
+        every rank's shard length; found with one all_gather when not given)."""
+        import torch
         from . import distributed as D
         from .engine import BatchResult
-        signals = np.ascontiguousarray(signals, dtype=np.float64)
+        assert branches > 0, "branches_number must be greater than 0"     # reference mmp.py:409
+        bank = self.device_bank()
+        if not isinstance(signals, torch.Tensor):
+            signals = np.ascontiguousarray(signals, dtype=np.float64)
+        if signals.ndim == 1:
+            signals = signals[None]
+        n = len(signals)
+        dist_on = sharded and D.is_distributed()
+        if dist_on and presharded:
+            lo, hi = 0, n
+            if shard_sizes is None:
+                shard_sizes = [None] * D.world_size()
+                torch.distributed.all_gather_object(shard_sizes, n)
+        elif dist_on:
+            lo, hi = D.shard_range(n, D.rank(), D.world_size())
+            shard_sizes = D.shard_sizes(n, D.world_size())
+        else:
+            lo, hi = 0, n
+        parts, stats = [], None
+        for c0 in range(lo, hi, self.PIPELINE_CHUNK):
+            rows, st = bank.mmpdf_records(signals[c0:min(hi, c0 + self.PIPELINE_CHUNK)], max_sparsity, connections,
+                                          branches, dissimilarity, want_coef=want_coef, fields=fields)
+            parts.append(rows)
+            stats = st.clone() if stats is None else stats + st
+        if not parts:                                    # an empty shard (fewer signals than ranks) still joins the gather
+            width = BatchResult.record_width(max_sparsity, connections, branches, want_coef, fields)
+            parts = [torch.zeros((0, width), dtype=torch.uint8, device=getattr(bank, "device", "cpu"))]
+            stats = torch.zeros(4, dtype=torch.int32)
+        local = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+        if not dist_on:
+            return local, stats
+        if torch.distributed.get_backend() != "nccl":
+            local = local.cpu()
+        return D.gather_rows(local, shard_sizes, out=recv), stats
+
+    def _batch(self, signals, max_sparsity, connections, branches, dissimilarity, want_coef=False,
+               sharded=False, fields="all"):
+        """signals [S, N] -> (BatchResult on the host, amortised seconds per signal); (None, dt) on ranks != 0
+        of a sharded call.  ``fields="rec"`` keeps the node tables on the device and brings back only the
+        per-sparsity winners (the sparVar path)."""
+        from . import distributed as D
+        from .engine import BatchResult
+        if not hasattr(signals, "device"):
+            signals = np.ascontiguousarray(signals, dtype=np.float64)
         if signals.ndim == 1:
             signals = signals[None]
         assert branches > 0, "branches_number must be greater than 0"     # reference mmp.py:409
         S = len(signals)
-        bank = self.device_bank()
         t0 = time.time()
-        lo, hi = D.shard_range(S, D.rank(), D.world_size()) if sharded else (0, S)
-        if not (sharded and D.is_distributed()) and S <= self.PIPELINE_CHUNK:
-            res = bank.mmpdf_batch(signals, max_sparsity, connections, branches, dissimilarity, want_coef=want_coef)
+        if not (sharded and D.is_distributed()) and S <= self.PIPELINE_CHUNK and fields == "all":
+            res = self.device_bank().mmpdf_batch(signals, max_sparsity, connections, branches, dissimilarity,
+                                                 want_coef=want_coef)
             return res, (time.time() - t0) / max(1, S)
-        width = sum(int(np.prod(shp)) * np.dtype(dt).itemsize
-                    for _, dt, shp in BatchResult.field_specs(max_sparsity, connections, branches, want_coef))
-        parts, stats = [np.zeros((0, width), np.uint8)], np.zeros(4, np.int32)
-        for c0 in range(lo, hi, self.PIPELINE_CHUNK):
-            r = bank.mmpdf_batch(signals[c0:min(hi, c0 + self.PIPELINE_CHUNK)], max_sparsity, connections,
-                                 branches, dissimilarity, want_coef=want_coef)
-            parts.append(r.to_records())
-            stats += r.stats
-        raw = np.concatenate(parts, axis=0)
-        if sharded:
-            raw = D.gather_records(raw, S)
+        raw, stats = self._records(signals, max_sparsity, connections, branches, dissimilarity, want_coef, fields,
+                                   sharded)
         dt = (time.time() - t0) / max(1, S)
         if raw is None:
             return None, dt
-        return BatchResult.from_records(raw, max_sparsity, connections, branches, want_coef, stats), dt
+        return BatchResult.from_records(raw.cpu().numpy(), max_sparsity, connections, branches, want_coef,
+                                        stats.cpu().numpy(), fields), dt
 
     def _sparvar_records(self, res, s, delay):
         """[{'mse','path','atoms','delay'}] for k = 1..max_sparsity (reference mmp.py:577-606)."""
@@ -456,7 +496,9 @@ class CSCDictionary:
                 for f, (shp, dt) in enumerate(zip(shapes, dts))]
         if not (sharded and D.is_distributed()):
             return arrs
-        raw = np.concatenate([np.ascontiguousarray(a).reshape(hi - lo, -1).view(np.uint8) for a in arrs], axis=1)
+        # explicit per-field widths: reshape(0, -1) of an empty shard (fewer signals than ranks) is an error
+        raw = np.concatenate([np.ascontiguousarray(a).view(np.uint8).reshape(hi - lo, int(np.prod(shp)) * np.dtype(dt).itemsize)
+                              for a, shp, dt in zip(arrs, shapes, dts)], axis=1)
         raw = D.gather_records(raw, S)
         if raw is None:
             return None
@@ -604,10 +646,23 @@ class CSCDictionary:
         np.asarray accepts); returns a ``SparVarBatch`` (None on ranks != 0 when ``sharded`` under
         torch.distributed).  Same numbers as the per-signal records of mmpdfSparVarFromDict
         (reference :1047-1071)."""
-        res, dt = self._batch(signals, max_sparsity, connections_level, nb_branches, dissimilarity, sharded=sharded)
+        res, dt = self._batch(signals, max_sparsity, connections_level, nb_branches, dissimilarity, sharded=sharded,
+                              fields="rec")
         if res is None:
             return None
         return SparVarBatch(self, res, dt)
+
+    def mmpdfSparVarRecords(self, signals, connections_level: int = 3, dissimilarity: float = 0.8,
+                            nb_branches: int = 10, max_sparsity: int = 10, sharded: bool = False,
+                            presharded: bool = False, shard_sizes=None, recv=None):
+        """Device-in / device-out form of mmpdfSparVarBatch: ``signals`` may be a float64 tensor already in
+        HBM; returns the [S, (16 + 8 K) K] uint8 sparVar records (K f64 mse | K x 2 i32 leaf | K x K x 2 i32
+        (pos, atom) per signal, BatchResult.field_specs(fields="rec")) as a tensor on this process's GPU --
+        after the one gather on rank 0, None on the other ranks, when ``sharded`` under torch.distributed.
+        Nothing passes through the host.  ``SparVarBatch.from_records`` turns the tensor into results."""
+        rows, _ = self._records(signals, max_sparsity, connections_level, nb_branches, dissimilarity, False, "rec",
+                                sharded, presharded, shard_sizes, recv)
+        return rows
 
     # ------------------------------------------------------------------------------------------
     # pipelines: JSON DB -> one batched device call -> JSON (reference :683-756, 1073-1152)
@@ -712,7 +767,8 @@ class CSCDictionary:
             print(f"MMP-DF Pipeline from {input_filename} with {len(data['signals'])} signals")
         mmpdf_results = self._grouped(
             data["signals"], lambda sd: len(sd["signal"]),
-            lambda k, sig: self._batch(sig, max_sparsity, connections, branches, dissimilarity, sharded=True),
+            lambda k, sig: self._batch(sig, max_sparsity, connections, branches, dissimilarity, sharded=True,
+                                       fields="rec"),
             lambda sd, res, row, dt, k: {"id": sd["id"], "snr": sd["snr"],
                                          "results": self._sparvar_records(res, row, dt)})
         if mmpdf_results is None:
@@ -742,6 +798,14 @@ class SparVarBatch:
 
     def __len__(self):
         return len(self.mse)
+
+    @classmethod
+    def from_records(cls, dictionary, rows, connections, branches, max_sparsity, seconds_per_signal=0.0):
+        """From the [S, (16 + 8 K) K] uint8 records of mmpdfSparVarRecords (tensor or array)."""
+        from .engine import BatchResult
+        raw = rows.cpu().numpy() if hasattr(rows, "cpu") else np.asarray(rows)
+        return cls(dictionary, BatchResult.from_records(raw, max_sparsity, connections, branches, False,
+                                                        fields="rec"), seconds_per_signal)
 
     def path(self, s, k) -> str:
         return self._res.path_str(k, int(self.leaf[s, k - 1]))

@@ -58,35 +58,46 @@ class BatchResult:
     _FIELDS = ("node_pos", "node_atom", "node_mse", "node_coef", "rec_mse", "rec_leaf", "rec_sel")
 
     def __len__(self):
-        return self.node_pos.shape[0]
+        return self.rec_mse.shape[0]
 
     @staticmethod
-    def field_specs(max_sparsity, connections, branches, want_coef):
-        """(name, dtype, per-signal shape) of the fixed-size record of one signal."""
+    def field_specs(max_sparsity, connections, branches, want_coef, fields="all"):
+        """(name, dtype, per-signal shape) of the fixed-size record of one signal.  ``fields="rec"``: the
+        per-sparsity winners only (what the sparVar path needs and what its gather sends: (16 + 8 K) K bytes,
+        280 B at K = 5); ``"all"``: the node tables in front of them."""
         sizes, NN = _lib.tree_shape(max_sparsity, connections, branches)
         K = max_sparsity
-        specs = [("node_pos", np.int32, (NN,)), ("node_atom", np.int32, (NN,)), ("node_mse", np.float64, (NN,))]
-        if want_coef:
-            specs.append(("node_coef", np.float64, (NN, K)))
+        specs = []
+        if fields == "all":
+            specs += [("node_pos", np.int32, (NN,)), ("node_atom", np.int32, (NN,)), ("node_mse", np.float64, (NN,))]
+            if want_coef:
+                specs.append(("node_coef", np.float64, (NN, K)))
+        elif fields != "rec":
+            raise ValueError(f"fields must be 'all' or 'rec', not {fields!r}")
         specs += [("rec_mse", np.float64, (K,)), ("rec_leaf", np.int32, (K, 2)), ("rec_sel", np.int32, (K, K, 2))]
         return specs
 
-    def to_records(self) -> np.ndarray:
+    @classmethod
+    def record_width(cls, max_sparsity, connections, branches, want_coef, fields="all"):
+        return sum(int(np.prod(shp)) * np.dtype(dt).itemsize
+                   for _, dt, shp in cls.field_specs(max_sparsity, connections, branches, want_coef, fields))
+
+    def to_records(self, fields="all") -> np.ndarray:
         """[S, rec_bytes] uint8: the per-signal fixed-size records that travel in the result gather
-        (csc_amd.distributed.gather_records)."""
+        (csc_amd.distributed.gather_rows)."""
         S = len(self)
         cols = [np.ascontiguousarray(getattr(self, n)).reshape(S, -1).view(np.uint8)
                 for n, _, _ in self.field_specs(self.max_sparsity, self.connections, self.branches,
-                                                self.node_coef is not None)]
+                                                self.node_coef is not None, fields)]
         return np.concatenate(cols, axis=1) if S else np.zeros((0, sum(c.shape[1] for c in cols)), np.uint8)
 
     @classmethod
-    def from_records(cls, raw, max_sparsity, connections, branches, want_coef, stats=None):
+    def from_records(cls, raw, max_sparsity, connections, branches, want_coef, stats=None, fields="all"):
         sizes, NN = _lib.tree_shape(max_sparsity, connections, branches)
         offs = [int(x) for x in np.concatenate([[0], np.cumsum(sizes)[:-1]])]
         S = raw.shape[0]
-        f, at = {"node_coef": None}, 0
-        for n, dt, shp in cls.field_specs(max_sparsity, connections, branches, want_coef):
+        f, at = {"node_pos": None, "node_atom": None, "node_mse": None, "node_coef": None}, 0
+        for n, dt, shp in cls.field_specs(max_sparsity, connections, branches, want_coef, fields):
             nb = int(np.prod(shp)) * np.dtype(dt).itemsize
             f[n] = np.ascontiguousarray(raw[:, at:at + nb]).view(dt).reshape((S,) + shp)
             at += nb
@@ -117,7 +128,8 @@ class DeviceBank:
     def __init__(self, bank64: np.ndarray, device=None):
         if not torch.cuda.is_available():
             raise RuntimeError("csc_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
-        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        from . import distributed as D
+        self.device = D.local_device() if device is None else torch.device(device)
         self.lib = _lib.lib()
         bank64 = np.ascontiguousarray(bank64, dtype=np.float64)
         self.K, self.L = bank64.shape
@@ -197,7 +209,6 @@ class DeviceBank:
                                                   _ptr(d_idx), _ptr(d_sup), M, kmax, _ptr(coef), _ptr(mse),
                                                   _ptr(approx), _ptr(stats), _stream(self.device)),
                        "csc_project_batch")
-            torch.cuda.synchronize(self.device)
         return (coef.cpu().numpy(), mse.cpu().numpy(), approx.cpu().numpy() if want_approx else None,
                 int(stats[1].item()))
 
@@ -215,7 +226,6 @@ class DeviceBank:
             _lib.check(self.lib.csc_match_batch(_ptr(self.bank64), self.K, self.L, _ptr(d_t), t.shape[1], _ptr(d_a),
                                                 a.shape[1], M, float(pos_err_threshold), float(corr_err_threshold),
                                                 _ptr(tp), _stream(self.device)), "csc_match_batch")
-            torch.cuda.synchronize(self.device)
         return tp.cpu().numpy()
 
     # ---- batched matching pursuit (mp / mpFromDict / mpSparVarFromDict) -----------------------------------
@@ -239,7 +249,6 @@ class DeviceBank:
             _lib.check(self.lib.csc_mp_batch(_ptr(self.bank32t), _ptr(self.bank64), self.K, self.L, _ptr(sig), S, N,
                                              I, _ptr(ws), ws.numel() * 8, _ptr(pos), _ptr(atom), _ptr(mse),
                                              _ptr(mask), _ptr(stats), _stream(dev)), "csc_mp_batch")
-            torch.cuda.synchronize(dev)
         return pos.cpu().numpy(), atom.cpu().numpy(), mse.cpu().numpy(), mask.cpu().numpy()
 
     # ---- batched MMP-DF ------------------------------------------------------------------------------
@@ -254,10 +263,9 @@ class DeviceBank:
             if out is None:
                 ws_bytes = self.lib.csc_mmpdf_workspace_bytes(S, N, max_sparsity, connections, branches)
                 K = max_sparsity
-                # the per-sparsity records live in ONE buffer (what the multi-GPU gather sends):
-                # [S][K] f64 mse | [S][K][2] i32 leaf | [S][K][K][2] i32 (pos, atom)
-                rec = torch.empty(S * K * (16 + 8 * K), dtype=torch.uint8, device=dev)
-                o1, o2 = S * K * 8, S * K * 16
+                # the per-sparsity records: one contiguous record per signal (CSC_FLAG_RECORDS_AOS), exactly the
+                # rows the multi-GPU gather sends: K f64 mse | K x 2 i32 leaf | K x K x 2 i32 (pos, atom)
+                rec = torch.empty((S, K * (16 + 8 * K)), dtype=torch.uint8, device=dev)
                 out = {
                     "ws": torch.empty(max(ws_bytes, 8) // 8, dtype=torch.float64, device=dev),
                     "node_pos": torch.empty((S, NN), dtype=torch.int32, device=dev),
@@ -265,19 +273,55 @@ class DeviceBank:
                     "node_mse": torch.empty((S, NN), dtype=torch.float64, device=dev),
                     "node_coef": torch.empty((S, NN, K), dtype=torch.float64, device=dev) if want_coef else None,
                     "rec_buf": rec,
-                    "rec_mse": rec[:o1].view(torch.float64).view(S, K),
-                    "rec_leaf": rec[o1:o2].view(torch.int32).view(S, K, 2),
-                    "rec_sel": rec[o2:].view(torch.int32).view(S, K, K, 2),
+                    "rec_mse": rec[:, :8 * K].view(torch.float64),
+                    "rec_leaf": rec[:, 8 * K:16 * K].view(torch.int32).unflatten(1, (K, 2)),
+                    "rec_sel": rec[:, 16 * K:].view(torch.int32).unflatten(1, (K, K, 2)),
                     "stats": torch.zeros(4, dtype=torch.int32, device=dev),
                 }
-            rc = self.lib.csc_mmpdf_batch(
-                _ptr(self.bank32t), _ptr(self.bank64), _ptr(sim), self.K, self.L, _ptr(sig), S, N,
-                max_sparsity, connections, branches, (1 if self.fp32_only else 0) | (0 if self.lean else 2), _ptr(out["ws"]), out["ws"].numel() * 8,
-                _ptr(out["node_pos"]), _ptr(out["node_atom"]), _ptr(out["node_mse"]), _ptr(out["node_coef"]),
-                _ptr(out["rec_mse"]), _ptr(out["rec_leaf"]), _ptr(out["rec_sel"]), _ptr(out["stats"]),
-                _stream(dev))
-            _lib.check(rc, "csc_mmpdf_batch")
+            flags = (1 if self.fp32_only else 0) | (0 if self.lean else 2) | 4          # 4 = CSC_FLAG_RECORDS_AOS
+            tail = (_ptr(out["node_pos"]), _ptr(out["node_atom"]), _ptr(out["node_mse"]), _ptr(out["node_coef"]),
+                    _ptr(out["rec_buf"]), None, None, _ptr(out["stats"]), _stream(dev))
+            head = (_ptr(self.bank32t), _ptr(self.bank64), _ptr(sim), self.K, self.L, _ptr(sig), S, N,
+                    max_sparsity, connections, branches, flags)
+            _lib.check(self.lib.csc_mmpdf_batch(*head, _ptr(out["ws"]), out["ws"].numel() * 8, *tail),
+                       "csc_mmpdf_batch")
         return out
+
+    @staticmethod
+    def pack_records(out, fields="rec", want_coef=False):
+        """Device tensors of mmpdf_launch -> [S, width] uint8 per-signal records on the device, in the layout of
+        BatchResult.field_specs.  "rec" is the buffer the kernel wrote, as it is; "all" puts the node tables in
+        front of it (one device concatenation).  Nothing goes through the host."""
+        if fields == "rec":
+            return out["rec_buf"]
+        S = out["rec_buf"].shape[0]
+        names = ["node_pos", "node_atom", "node_mse"] + (["node_coef"] if want_coef else [])
+        return torch.cat([out[n].contiguous().view(S, -1).view(torch.uint8) for n in names] + [out["rec_buf"]], dim=1)
+
+    def mmpdf_records(self, signals, max_sparsity, connections, branches, dissimilarity, want_coef=False,
+                      fields="rec"):
+        """signals [S, N] (host array or device tensor) -> ([S, width] uint8 records ON THE DEVICE, stats
+        tensor [4] int32 on the device).  What a rank hands to the result gather."""
+        sig = self._to_device(signals)
+        out = self.mmpdf_launch(sig, max_sparsity, connections, branches, dissimilarity,
+                                want_coef=want_coef and fields == "all")
+        with torch.cuda.device(self.device):
+            return self.pack_records(out, fields, want_coef), out["stats"]
+
+    def filter_product(self, signals, variant=0):
+        """Test aid (csc_filter_product): the fp16 filter product of every signal, [B, P, K] f32 in units of
+        ||signal||, the bound eps [B] the kernels assume for it and ||signal|| [B]; host arrays."""
+        sig = self._to_device(signals)
+        B, N = sig.shape
+        P = N - self.L + 1
+        with torch.cuda.device(self.device):
+            prod = torch.full((B, max(P, 0), self.K), float("nan"), dtype=torch.float32, device=self.device)
+            eps = torch.zeros(B, dtype=torch.float32, device=self.device)
+            nrm = torch.zeros(B, dtype=torch.float64, device=self.device)
+            _lib.check(self.lib.csc_filter_product(_ptr(self.bank32t), self.K, self.L, _ptr(sig), B, N, int(variant),
+                                                   _ptr(prod), _ptr(eps), _ptr(nrm), _stream(self.device)),
+                       "csc_filter_product")
+        return prod.cpu().numpy(), eps.cpu().numpy(), nrm.cpu().numpy()
 
     def mmpdf_batch(self, signals, max_sparsity, connections, branches, dissimilarity,
                     want_coef=True) -> BatchResult:

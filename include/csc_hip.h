@@ -26,13 +26,14 @@
 extern "C" {
 #endif
 
-#define CSC_ABI_VERSION 3
+#define CSC_ABI_VERSION 4
 #define CSC_TILE_COLS 144      /* atoms per column tile of the correlation kernel (9 x 16)   */
 #define CSC_TILE_ROWS 256      /* positions per row tile (4 waves x 4 x 16)                   */
 #define CSC_MAX_SPARSITY 16    /* largest tree depth / support size                           */
 #define CSC_MAX_CONNECTIONS 8  /* largest number of siblings per node                         */
 #define CSC_FLAG_FP32_ONLY 1   /* csc_mmpdf_batch flags: skip the fp16 matrix-core filter      */
 #define CSC_FLAG_NO_LEAN 2     /* keep single-child levels on the register-resident kernel      */
+#define CSC_FLAG_RECORDS_AOS 4 /* per-sparsity records as one contiguous record per signal      */
 
 int csc_abi_version(void);
 const char* csc_last_error(void);
@@ -99,6 +100,11 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
  *               src/csc/mmp.py:586) and of the FIRST minimum (np.argmin, src/csc/mmp.py:464)
  *   d_rec_sel   [S][max_sparsity][max_sparsity][2] int32  (pos, atom) root->leaf of the last-min
  *               leaf, -1 padded                                      (src/csc/mmp.py:257-265)
+ *               With CSC_FLAG_RECORDS_AOS the three d_rec_* arrays are ONE buffer of contiguous per-signal
+ *               records instead: d_rec_mse points to [S][(16 + 8 K) K] bytes, record s = K f64 mse | K x 2 i32
+ *               leaf | K x K x 2 i32 (pos, atom), K = max_sparsity (d_rec_leaf / d_rec_sel are ignored) -- the
+ *               rows the multi-GPU result gather sends as they are (replaces the list the joblib fan-out
+ *               returns, src/csc/dictionary.py:1147-1148)
  *   d_stats     [4] int32 or NULL (must be zeroed by the caller): [0] selections that fell back
  *               to the fp32 arg-max (candidate overflow), [1] re-selected activations (dead Cholesky
  *               columns), [2] number of fp64 re-scored candidates, [3] nodes the fp16 filter could not
@@ -114,6 +120,18 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
                     int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse,
                     double* d_node_coef, double* d_rec_mse, int32_t* d_rec_leaf,
                     int32_t* d_rec_sel, int32_t* d_stats, void* stream);
+
+/* Test aid: the fp16 matrix-core filter product that csc_mmpdf_batch only ever holds in registers, so that the
+ * rounding bound its exactness rests on can be checked directly (no counterpart in the reference; its
+ * correlations are float64, src/csc/dictionary.py:395-407).
+ *   d_prod [B][P][K] f32: product of signal b, scaled to unit norm and rounded to fp16, with the fp16 bank, in
+ *          units of ||signal_b||; variant 0 = the loop of the register-resident level kernel, 1 = the
+ *          column-group loop of the chain kernel
+ *   d_eps  [B] f32: the bound on |d_prod - float64 correlation / ||signal||| the kernels assume (their
+ *          candidate band is twice this);   d_norm [B] f64: ||signal_b||
+ * Covers what the filter covers: K <= 144, P <= 256, L <= 512, N <= 1024. */
+int csc_filter_product(const float* d_bank32t, int K, int L, const double* d_signals, int B, int N,
+                       int variant, float* d_prod, float* d_eps, double* d_norm, void* stream);
 
 /* Batched plain convolutional matching pursuit.  Replaces CSCDictionary.mp / mpFromDict /
  * mpSparVarFromDict (src/csc/dictionary.py:764-921): per iteration, correlations of the residual

@@ -54,6 +54,13 @@ class OracleBank:
                     r.rec_sel[s, k - 1, e] = (p, a)
         return r
 
+    def mmpdf_records(self, signals, max_sparsity, connections, branches, dissimilarity, want_coef=False,
+                      fields="rec"):
+        import torch
+        r = self.mmpdf_batch(signals, max_sparsity, connections, branches, dissimilarity,
+                             want_coef=want_coef and fields == "all")
+        return torch.from_numpy(r.to_records(fields)), torch.zeros(4, dtype=torch.int32)
+
     def mp_batch(self, signals, iterations):
         signals = np.atleast_2d(np.asarray(signals, dtype=np.float64))
         S, I = len(signals), iterations

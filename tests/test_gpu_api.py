@@ -300,6 +300,19 @@ def test_config2_vs_oracle_sample(dic, config2, oracle_dict):
             assert abs(res.node_mse[s, nid] - mse) <= 1e-9 * mse
 
 
+def test_config2_all_3200_vs_oracle(dic, config2):
+    """EVERY signal of config 2, every node, against the CPU oracle's trees (tests/golden/config2_trees.npz, written
+    by tests/golden/make_golden_config2.py with the oracle's 'direct' mode): positions and atoms bit-exact, MSE to
+    1e-9 relative."""
+    import hashlib
+    sigs, _, res = config2
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "config2_trees.npz"))
+    if hashlib.sha256(np.ascontiguousarray(sigs).tobytes()).hexdigest() != str(z["signals_sha256"]):
+        pytest.skip("this NumPy draws a different config-2 batch than the one the fixture was made from")
+    assert np.array_equal(res.node_pos, z["node_pos"]) and np.array_equal(res.node_atom, z["node_atom"])
+    assert np.allclose(res.node_mse, z["node_mse"], rtol=1e-9, atol=0)
+
+
 def test_recovery_of_true_atoms_at_high_snr(dic, config2):
     """sanity on the task itself: at 15 dB most true atoms are matched (position within 10, correlation >= 0.75) by the
     sparsity-matched record"""

@@ -148,3 +148,33 @@ def test_chunked_batch_is_position_invariant():
         assert np.array_equal(big.pos[c0:c0 + m], ref.pos[:m]), c0
         assert np.array_equal(big.atom[c0:c0 + m], ref.atom[:m]), c0
     assert big.path(n - 1, 5) == ref.path((n - 1) % S0, 5)
+
+
+def test_candidate_overflow_same_choice_in_register_and_tiled_kernels():
+    """More entries in the band than the candidate list holds (143 identical atoms: at every position the
+    143 correlations are bit-identical, so the maximum is shared by 143 entries): every kernel falls back to the
+    fp32 arg-max, lowest flattened index among the entries EQUAL to the maximum -- np.argmax's first occurrence
+    on the float64 values, which tie exactly here.  Register-resident kernel (P = 247), the same with the fp16
+    filter off, and the tiled kernel (the signal zero-extended to P = 260 positions) must agree with float64."""
+    import csc_amd
+    from csc_amd.engine import DeviceBank
+    d = csc_amd.ZSDictionary.from_values([0.03], [0.02], [1])
+    atom = d.getLocalDictionary()[0]
+    L = len(atom)
+    bank64 = np.tile(atom, (143, 1))
+    rng = np.random.default_rng(11)
+    N = L + 246
+    sigs = rng.standard_normal((6, N)) * 0.01
+    for i in range(6):
+        sigs[i, 30 * i + 5:30 * i + 5 + L] += atom
+    ext = np.concatenate([sigs, np.zeros((6, 13))], axis=1)            # P = 260: tiled kernel
+    want = [int(np.argmax(np.lib.stride_tricks.sliding_window_view(s, L) @ bank64.T)) for s in sigs]
+    assert want == [(30 * i + 5) * 143 for i in range(6)]
+    bank = DeviceBank(bank64)
+    got = {}
+    for name, (x, fp32) in {"register": (sigs, False), "register fp32": (sigs, True), "tiled": (ext, False)}.items():
+        bank.fp32_only = fp32
+        r = bank.mmpdf_batch(x, 1, 1, 1, 1.0)
+        assert r.stats[0] == 6, (name, r.stats)                         # every selection overflowed
+        got[name] = (r.node_pos[:, 0].astype(np.int64) * 143 + r.node_atom[:, 0]).tolist()
+    assert got["register"] == got["register fp32"] == got["tiled"] == want, got

@@ -312,7 +312,34 @@ d = csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.005), np.arange(0.
 bank = OracleBank(O.canonical_dictionary())
 d.device_bank = lambda: bank
 d.mmpdfSparVarPipelineFromDB(src, dst, 1, 3, 0.8, 3, 5)
-json.dump({"rank": rank, "calls": bank.calls}, open(dst + f".rank{rank}", "w"))
+calls = list(bank.calls)
+# 3. the gather on tensors (what the GPU path hands over: device rows in, device rows out), uneven shards
+import torch
+lo, hi = D.shard_range(5, rank, world)
+rows = torch.arange(lo, hi, dtype=torch.uint8)[:, None].repeat(1, 3)
+got = D.gather_rows(rows, D.shard_sizes(5, world))
+assert (got is None) == (rank != 0)
+if rank == 0:
+    assert isinstance(got, torch.Tensor) and got.shape == (5, 3) and got[:, 0].tolist() == [0, 1, 2, 3, 4]
+# 4. fewer signals than ranks: rank 1's shard is empty and still has to join the one gather (OMP / MMP-DF and MP cores)
+sigs = np.array([sd["signal"] for sd in json.load(open(src))["signals"]])
+res, _ = d._batch(sigs[:1], 2, 1, 1, 1.0, want_coef=True, sharded=True)
+assert (res is None) == (rank != 0)
+if rank == 0:
+    assert len(res) == 1 and res.node_coef.shape == (1, 2, 2)
+arrs = d._mp_batch(sigs[:1], 2, sharded=True)
+assert (arrs is None) == (rank != 0)
+if rank == 0:
+    assert arrs[0].shape == (1, 2) and arrs[3].shape == (1, 2, 2)
+# 5. pre-sharded device-level call (bench.py's config-5 leg): every rank passes its own rows
+mine = sigs[:2] if rank == 0 else sigs[2:3]
+rec = d.mmpdfSparVarRecords(mine, 3, 0.8, 3, 5, sharded=True, presharded=True)
+assert (rec is None) == (rank != 0)
+if rank == 0:
+    b = csc_amd.dictionary.SparVarBatch.from_records(d, rec, 3, 3, 5)
+    whole = d.mmpdfSparVarBatch(sigs[:3], 3, 0.8, 3, 5)
+    assert len(b) == 3 and np.array_equal(b.mse, whole.mse) and np.array_equal(b.pos, whole.pos)
+json.dump({"rank": rank, "calls": calls}, open(dst + f".rank{rank}", "w"))
 dist.barrier()
 dist.destroy_process_group()
 '''
