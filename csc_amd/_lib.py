@@ -43,6 +43,9 @@ def lib():
             "csc_mmpdf_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
             "csc_mmpdf_batch": (i32, [vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, sz,
                                       vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+            "csc_mmpdf_batch_static": (i32, [vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32,
+                                             vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+            "csc_static_scratch_bytes": (sz, []),
             "csc_filter_product": (i32, [vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp]),
             "csc_mp_batch": (i32, [vp, vp, i32, i32, vp, i32, i32, i32, vp, sz, vp, vp, vp, vp, vp, vp]),
             "csc_match_batch": (i32, [vp, i32, i32, vp, i32, vp, i32, i32, dbl, dbl, vp, vp]),
@@ -63,7 +66,7 @@ def lib():
 
 EXPORTS = ("csc_abi_version", "csc_last_error", "csc_bank32_elems", "csc_sim_words", "csc_bank_pack",
            "csc_similarity_table", "csc_correlate", "csc_tree_nodes", "csc_mmpdf_workspace_bytes",
-           "csc_mmpdf_batch", "csc_filter_product",
+           "csc_mmpdf_batch", "csc_mmpdf_batch_static", "csc_static_scratch_bytes", "csc_filter_product",
            "csc_mp_batch", "csc_project_batch", "csc_match_batch", "csc_timer_create", "csc_timer_destroy", "csc_timer_attach",
            "csc_timer_reset", "csc_timer_count", "csc_timer_read")
 

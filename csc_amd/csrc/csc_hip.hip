@@ -2563,3 +2563,5 @@ int csc_prof_read(unsigned long long* out32, int reset) {
 #endif
 
 }  // extern "C"
+
+#include "csc_static_scratch.inc"   // csc_mmpdf_batch_static: the entry point that allocates nothing

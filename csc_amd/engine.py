@@ -253,15 +253,17 @@ class DeviceBank:
 
     # ---- batched MMP-DF ------------------------------------------------------------------------------
     def mmpdf_launch(self, sig: torch.Tensor, max_sparsity, connections, branches, dissimilarity,
-                     want_coef=True, out=None):
-        """Enqueue one csc_mmpdf_batch on the current stream; returns the dict of device tensors."""
+                     want_coef=True, out=None, static_scratch=False):
+        """Enqueue one csc_mmpdf_batch on the current stream; returns the dict of device tensors.
+        ``static_scratch``: go through csc_mmpdf_batch_static (no workspace, nothing allocated by the call
+        when ``out`` is passed; batches up to the library's static device array)."""
         S, N = sig.shape
         sizes, NN = _lib.tree_shape(max_sparsity, connections, branches)
         dev = self.device
         sim = self.similarity_table(N, dissimilarity) if connections > 1 else None
         with torch.cuda.device(dev):
             if out is None:
-                ws_bytes = self.lib.csc_mmpdf_workspace_bytes(S, N, max_sparsity, connections, branches)
+                ws_bytes = 0 if static_scratch else self.lib.csc_mmpdf_workspace_bytes(S, N, max_sparsity, connections, branches)
                 K = max_sparsity
                 # the per-sparsity records: one contiguous record per signal (CSC_FLAG_RECORDS_AOS), exactly the
                 # rows the multi-GPU gather sends: K f64 mse | K x 2 i32 leaf | K x K x 2 i32 (pos, atom)
@@ -283,8 +285,11 @@ class DeviceBank:
                     _ptr(out["rec_buf"]), None, None, _ptr(out["stats"]), _stream(dev))
             head = (_ptr(self.bank32t), _ptr(self.bank64), _ptr(sim), self.K, self.L, _ptr(sig), S, N,
                     max_sparsity, connections, branches, flags)
-            _lib.check(self.lib.csc_mmpdf_batch(*head, _ptr(out["ws"]), out["ws"].numel() * 8, *tail),
-                       "csc_mmpdf_batch")
+            if static_scratch:
+                _lib.check(self.lib.csc_mmpdf_batch_static(*head, *tail), "csc_mmpdf_batch_static")
+            else:
+                _lib.check(self.lib.csc_mmpdf_batch(*head, _ptr(out["ws"]), out["ws"].numel() * 8, *tail),
+                           "csc_mmpdf_batch")
         return out
 
     @staticmethod

@@ -34,6 +34,7 @@ extern "C" {
 #define CSC_FLAG_FP32_ONLY 1   /* csc_mmpdf_batch flags: skip the fp16 matrix-core filter      */
 #define CSC_FLAG_NO_LEAN 2     /* keep single-child levels on the register-resident kernel      */
 #define CSC_FLAG_RECORDS_AOS 4 /* per-sparsity records as one contiguous record per signal      */
+#define CSC_STATIC_SCRATCH_BYTES (64u << 20)   /* static device scratch of csc_mmpdf_batch_static      */
 
 int csc_abi_version(void);
 const char* csc_last_error(void);
@@ -120,6 +121,24 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
                     int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse,
                     double* d_node_coef, double* d_rec_mse, int32_t* d_rec_leaf,
                     int32_t* d_rec_sel, int32_t* d_stats, void* stream);
+
+/* csc_mmpdf_batch without a workspace argument and without any allocation.  NO COUNTERPART IN THE REFERENCE
+ * (pure Python, it allocates freely): this entry point exists for callers that cannot call hipMalloc -- code
+ * under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same arguments, results and
+ * kernels as csc_mmpdf_batch; the node workspace (two generations of node residuals + the chain flags) lives in
+ * a file-scope `static __device__` array of CSC_STATIC_SCRATCH_BYTES (64 MiB) that every GPU the library runs
+ * on holds until the process ends.  The call allocates and frees nothing (no hipMalloc / hipFree, no library
+ * allocator); a batch whose csc_mmpdf_workspace_bytes(...) exceeds the array is refused with -10 (config 2:
+ * up to 1843 signals per call).  Every call on one GPU shares that GPU's array: calls that overlap on one GPU
+ * (two streams, two host threads) race -- serialise them or use csc_mmpdf_batch with separate workspaces.
+ * csc_static_scratch_bytes() returns the array's size. */
+size_t csc_static_scratch_bytes(void);
+int csc_mmpdf_batch_static(const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
+                           int K, int L, const double* d_signals, int S, int N,
+                           int max_sparsity, int connections, int branches, int flags,
+                           int32_t* d_node_pos, int32_t* d_node_atom, double* d_node_mse,
+                           double* d_node_coef, double* d_rec_mse, int32_t* d_rec_leaf,
+                           int32_t* d_rec_sel, int32_t* d_stats, void* stream);
 
 /* Test aid: the fp16 matrix-core filter product that csc_mmpdf_batch only ever holds in registers, so that the
  * rounding bound its exactness rests on can be checked directly (no counterpart in the reference; its

@@ -1,0 +1,71 @@
+"""GPU test of csc_mmpdf_batch_static, the entry point that allocates nothing (include/csc_hip.h): called through
+the C ABI on two batches in a row -- the second smaller, so that the static device scratch still holds the first
+call's residuals and chain flags -- its node tables and records must equal csc_mmpdf_batch's bit for bit, and the
+calls themselves must not allocate device memory.  Collected last (test_zz_*): the round's end runs pytest -x."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("node_pos", "node_atom", "node_mse", "node_coef", "rec_buf", "stats")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def test_static_scratch_entry_equals_workspace_entry(golden_signals):
+    import torch
+    import csc_amd
+    from csc_amd import _lib
+    d = csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.005), np.arange(0.010, 0.036, 0.002), [1])
+    bank = d.device_bank()
+    lib, dev = bank.lib, bank.device
+    assert lib.csc_static_scratch_bytes() == 64 << 20
+    sigs = golden_signals["signals"]
+    big = torch.from_numpy(np.concatenate([sigs, sigs[::-1] * 0.5, sigs * 2.0])).to(dev)      # 192 signals
+    small = torch.from_numpy(np.ascontiguousarray(sigs[5:42])).to(dev)                        # 37 signals
+    calls = 0
+    for (c, B, K) in ((3, 3, 5), (4, 64, 4)):
+        for sig in ((big, small) if B == 3 else (big[:60], small[:20])):    # second call: smaller input, dirty scratch
+            ref = bank.mmpdf_launch(sig, K, c, B, 0.8, want_coef=True)
+            # fresh output tensors with the same layout; no workspace is passed
+            S, N = sig.shape
+            _, NN = _lib.tree_shape(K, c, B)
+            mine = {"node_pos": torch.full((S, NN), -7, dtype=torch.int32, device=dev),
+                    "node_atom": torch.full((S, NN), -7, dtype=torch.int32, device=dev),
+                    "node_mse": torch.full((S, NN), -7.0, dtype=torch.float64, device=dev),
+                    "node_coef": torch.full((S, NN, K), -7.0, dtype=torch.float64, device=dev),
+                    "rec_buf": torch.zeros((S, K * (16 + 8 * K)), dtype=torch.uint8, device=dev),
+                    "stats": torch.zeros(4, dtype=torch.int32, device=dev)}
+            sim = bank.similarity_table(N, 0.8)
+            torch.cuda.synchronize(dev)
+            before = torch.cuda.memory_stats(dev)["allocation.all.allocated"], torch.cuda.mem_get_info(dev)[0]
+            rc = lib.csc_mmpdf_batch_static(_ptr(bank.bank32t), _ptr(bank.bank64), _ptr(sim), bank.K, bank.L, _ptr(sig), S, N,
+                                            K, c, B, 4, _ptr(mine["node_pos"]), _ptr(mine["node_atom"]),
+                                            _ptr(mine["node_mse"]), _ptr(mine["node_coef"]), _ptr(mine["rec_buf"]), None,
+                                            None, _ptr(mine["stats"]), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            _lib.check(rc, "csc_mmpdf_batch_static")
+            torch.cuda.synchronize(dev)
+            after = torch.cuda.memory_stats(dev)["allocation.all.allocated"], torch.cuda.mem_get_info(dev)[0]
+            assert after[0] == before[0], "the call went through torch's allocator"
+            calls += 1
+            if calls > 1:                                          # (the first call may page the library's image in)
+                assert after[1] >= before[1] - (1 << 20), "device memory was allocated by the call"
+            for n in NAMES:
+                assert torch.equal(mine[n], ref[n]), (n, c, B, K, S)
+    # sizes beyond the static array are refused with a clear error, nothing is launched
+    S_big = 4000
+    sig = torch.zeros((S_big, 738), dtype=torch.float64, device=dev)
+    need = lib.csc_mmpdf_workspace_bytes(S_big, 738, 5, 3, 3)
+    assert need > lib.csc_static_scratch_bytes()
+    rc = lib.csc_mmpdf_batch_static(_ptr(bank.bank32t), _ptr(bank.bank64), _ptr(bank.similarity_table(738, 0.8)), bank.K,
+                                    bank.L, _ptr(sig), S_big, 738, 5, 3, 3, 0, _ptr(sig), _ptr(sig), _ptr(sig), None, None,
+                                    None, None, None, None)
+    assert rc == -10 and b"static" in lib.csc_last_error()
+    # the high-level switch goes the same way
+    a = bank.mmpdf_launch(small, 5, 3, 3, 0.8, want_coef=False, static_scratch=True)
+    b = bank.mmpdf_launch(small, 5, 3, 3, 0.8, want_coef=False)
+    assert torch.equal(a["rec_buf"], b["rec_buf"])
