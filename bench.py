@@ -54,7 +54,7 @@ SIGNAL_LENGTH, PER_CELL = 738, 200
 SNR_LEVELS, SPARSITY_LEVELS = [0, 5, 10, 15], [2, 3, 4, 5]
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 FP16_MFMA_PEAK_TFLOPS = 2500.0     # same guide, "Peak BF16/FP16 MFMA": ~2.5 PF dense
-CPU_SAMPLE = [i * PER_CELL + 7 for i in (0, 3, 5, 6, 9, 10, 12, 15)]   # one signal in 8 of the 16 cells
+CPU_SAMPLE = [i * PER_CELL + o for i in range(16) for o in (7, 107)]    # two signals of every (snr, sparsity) cell: ~25 CPU-s
 CONFIG5_PER_RANK = 125000
 TRAFFIC_PROFILE = os.path.join("profiles", "r02_hbm_traffic.json")
 
@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-only comparison run (profiling)")
     ap.add_argument("--no-config5", action="store_true", help="skip the 125 000-signals-per-rank leg")
+    ap.add_argument("--fp32-only", action="store_true",
+                    help="diagnostic (profiling the fp32 leg): the timed loop itself runs with CSC_FLAG_FP32_ONLY")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -179,6 +181,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # cuda:LOCAL_RANK by itself
     bank = dic.device_bank()
     assert bank.device == dev == D.local_device(), (bank.device, dev)
+    if a.fp32_only:
+        bank.fp32_only = True
+        a.no_fp32_leg = True
     K, L = bank.K, bank.L
     P = N - L + 1
     sizes, NN = _lib.tree_shape(MAX_SPARSITY, CONNECTIONS, BRANCHES)
@@ -363,7 +368,8 @@ def main():
         line = {
             "metric": "signals/sec for MMP-DF (3 branches, sparsity<=5)", "value": value, "unit": "signals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (diagnostic run: --fp32-only)" if a.fp32_only else "f16",
             "data": "synthetic",
             "config": {"workload": "config 2: 3200-signal sparVar sweep (sparsity 2-5 x SNR 0-15 dB, 200 each, "
                                    "constrained), MMP-DF connections 3 / branches 3 / max sparsity 5 / "

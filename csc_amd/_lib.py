@@ -55,6 +55,12 @@ def lib():
             "csc_timer_reset": (None, [vp]),
             "csc_timer_count": (i32, [vp]),
             "csc_timer_read": (i32, [vp, C.POINTER(C.c_float), C.POINTER(i32), i32]),
+            "csc_generate_signals": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, i32, dbl, dbl, C.c_uint64, C.c_uint64,
+                                           vp, vp, vp, vp]),
+            "csc_sparvar_json_write": (i32, [C.c_char_p, i32, vp, C.c_int64, i32, i32, vp, vp, vp, dbl, vp, vp, vp, i32,
+                                             i32, i32]),
+            "csc_format_double": (i32, [dbl, C.c_char_p, i32]),
+            "csc_json_last_error": (C.c_char_p, []),
             "csc_project_batch": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
         }
         for name, (res, args) in sig.items():
@@ -68,7 +74,8 @@ EXPORTS = ("csc_abi_version", "csc_last_error", "csc_bank32_elems", "csc_sim_wor
            "csc_similarity_table", "csc_correlate", "csc_tree_nodes", "csc_mmpdf_workspace_bytes",
            "csc_mmpdf_batch", "csc_mmpdf_batch_static", "csc_static_scratch_bytes", "csc_filter_product",
            "csc_mp_batch", "csc_project_batch", "csc_match_batch", "csc_timer_create", "csc_timer_destroy", "csc_timer_attach",
-           "csc_timer_reset", "csc_timer_count", "csc_timer_read")
+           "csc_timer_reset", "csc_timer_count", "csc_timer_read", "csc_sparvar_json_write", "csc_format_double", "csc_generate_signals",
+           "csc_json_last_error")
 
 
 def check(rc, what):

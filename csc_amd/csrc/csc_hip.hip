@@ -57,6 +57,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // Development aid (make prof): per-phase shader-clock totals of the level kernels, summed over workgroups
 // (slots 0-15: mmp_level_kernel / the tiled kernel, 16-31: mmp_level_lean_kernel; scripts/phase_prof.py names them).
 #ifdef CSC_PHASE_PROF
+// in-loop stamps of the tiled fp16 product (wave 0 only; s_memtime: each stamp also waits for the wave's LDS reads)
+#define T3_CLK() ((unsigned)__builtin_amdgcn_s_memtime())
+#define T3_STAMP(i) do { const unsigned n_ = T3_CLK(); t3acc[i] += n_ - t3last; t3last = n_; } while (0)
 #define PROF_BUCKETS 256                // the counters are spread over buckets (block index) to keep the atomics apart
 __device__ unsigned long long g_prof[32][PROF_BUCKETS];
 #define PROF_FIELDS unsigned long long prof_t; int prof_base;
@@ -68,6 +71,7 @@ __device__ unsigned long long g_prof[32][PROF_BUCKETS];
 #define PROF_FIELDS
 #define PROF_INIT(base)
 #define PROF_MARK(i)
+#define T3_STAMP(i)
 #endif
 
 static thread_local char g_err[256] = "";
@@ -517,6 +521,33 @@ __global__ void bank_pack16_kernel(const double* __restrict__ bank64, int K, int
     out[i] = (k >= 0 && l < L) ? (_Float16)(float)bank64[(size_t)k * L + l] : (_Float16)0.f;
 }
 
+// The bank as a two-term fp16 number for the three-product filter of the tiled kernel (a ~ hi + lo to ~2^-22):
+// hi = fl16(a 2^sa), lo = fl16(a 2^sa - hi), same block layout as bank_pack16_kernel.  The power of two 2^sa (split_scale)
+// brings max_k ||a_k|| to [32, 64), which keeps the lo parts of all but the atoms' far tails out of the fp16
+// subnormals; the same function gives the level kernel the scale to undo.
+__device__ __host__ __forceinline__ float split_scale(float amax2) {
+    const float am = sqrtf(amax2);
+    if (!(am > 1e-3f && am < 1e2f)) return 1.f;
+    return exp2f(floorf(log2f(64.f / am)));
+}
+__global__ void bank_pack16s_kernel(const double* __restrict__ bank64, int K, int L, int nslab,
+                                    const int32_t* __restrict__ meta, const float* __restrict__ amax2,
+                                    _Float16* __restrict__ hi, _Float16* __restrict__ lo, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i & 7), col16 = (int)((i >> 3) & 15), kg = (int)((i >> 7) & 3);
+    size_t t = i / BLKF;
+    const int ni = (int)(t % NT); t /= NT;
+    const int slab = (int)(t % nslab);
+    const int tile = (int)(t / nslab);
+    const int k = meta[tile * META_INTS + 16 * ni + col16];
+    const int l = slab * SLAB + 8 * kg + j;
+    const double x = (k >= 0 && l < L) ? bank64[(size_t)k * L + l] * (double)split_scale(*amax2) : 0.0;
+    const _Float16 h = (_Float16)x;
+    hi[i] = h;
+    lo[i] = (_Float16)(x - (double)h);
+}
+
 // anorm2[k] = ||a_k||^2, amax2 = their maximum (one wave per atom)
 __global__ __launch_bounds__(64) void bank_norm_kernel(const double* __restrict__ bank64, int K, int L,
                                                        float* __restrict__ amax2, double* __restrict__ anorm2) {
@@ -534,6 +565,10 @@ __global__ __launch_bounds__(64) void bank_norm_kernel(const double* __restrict_
 __global__ void bank_mask_kernel(const float* __restrict__ tiles, int nslab, int32_t* __restrict__ meta) {
     __shared__ uint32_t m;
     const int slab = blockIdx.x, tile = blockIdx.y;
+    if (slab >= nslab) {                                               // the unused mask words of the tile: defined, zero
+        if (threadIdx.x == 0) meta[tile * META_INTS + CSC_TILE_COLS + slab] = 0;
+        return;
+    }
     if (threadIdx.x == 0) m = 0;
     __syncthreads();
     const float* blk = tiles + ((size_t)tile * nslab + slab) * SLABF;
@@ -1934,6 +1969,8 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled_kernel(const LevelArgs 
     size_t s;
     int j;
     node_of_block(Fd, s, j);
+    // launched behind mmp_level_tiled16_kernel: only the nodes its filter could not settle (workgroup-uniform)
+    if (a.flags && !a.flags[s * Fd + j]) return;
     const int stride = a.ts.pw[d];
     int nch = 0;
     for (int r = 0; r < a.connections; ++r) {
@@ -2045,6 +2082,488 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled_kernel(const LevelArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
+// the tiled level kernel on the fp16 matrix cores: a three-product filter
+// ------------------------------------------------------------------------------------------------
+// Same node, same unit-by-unit sweeps as mmp_level_tiled_kernel, but the correlations come from
+// v_mfma_f32_16x16x32_f16 (16x the fp32 rate) and still carry ~fp32 accuracy: both operands are two-term fp16
+// numbers -- residual r 2^6 / ||r|| = rh + rl, bank a 2^sa = ah + al, each to ~2^-22 relative (bank_pack16s_kernel) --
+// and a product is three MFMAs, rh ah + rh al + rl ah (rl al ~ 2^-22 is dropped), accumulated in fp32.  An entry, in
+// units of ||r||, is then off by at most
+//     eps3 = (2^-13 + 2^-20) am + 2^-29 sqrt(L) (1 + am),     am = max_k ||a_k||:
+// 2^-13 am for the fp32 accumulation of 3 L products (3 L 2^-24 <= 2^-13 up to L = 682; checked at launch), 3 x 2^-22 am
+// for the two operand splits and the dropped product, the last term for operands that are subnormal in fp16 after
+// scaling.  Every entry within 2 eps3 of the computed maximum is re-scored in float64, so the selection is the
+// float64 arg-max -- what the single-term filter cannot offer a finely sampled dictionary (its 2^-10 band holds
+// ~200 of 9570 atoms).  A unit here is (256 positions + a 16-row remainder tile) x 48 atoms (a column GROUP of a
+// bank tile): 48 accumulator VGPRs; the remainder tile (positions 256..271 of the row block, e.g. rows 256..259 of
+// P = 260) rides along in the same pass, its three column tiles dealt to waves 0..2 (3 MFMAs per slab and wave
+// instead of a second pass over the bank).
+// A node the filter cannot settle (more than CAND_CAP entries in the band, the value 0 of suppressed entries inside
+// it, NaN / Inf / extreme scales) is flagged; mmp_level_tiled_kernel, launched behind on the same level with the flag
+// array, redoes exactly the flagged nodes in fp32.
+// halves per shifted copy of the residual: the whole window (row blocks + remainder tile + atom slabs + one slab of
+// look-ahead), rounded up to 32 mod 128 so that the copy stride is 64 mod 256 bytes (conflict-free ds_read_b128, as R16_CS)
+static __host__ __device__ inline int r16t_stride(int P, int Lp) {
+    const int nrb_all = (P + CSC_TILE_ROWS - 1) / CSC_TILE_ROWS;
+    const bool rem = nrb_all > 1 && (P - (nrb_all - 1) * CSC_TILE_ROWS) <= 16;
+    const int need = (rem ? nrb_all - 1 : nrb_all) * CSC_TILE_ROWS + 16 + Lp + SLAB;
+    return ((need - 32 + 127) / 128) * 128 + 32;
+}
+#define TRING 4                        // group-slabs in the ring: one being multiplied, one landed, two copies in flight
+#define TG_BLK (2 * NG * BLKF)         // halves of one group-slab: 3 hi blocks, 3 lo blocks
+#define EPS3_ACC 1.220703125e-04f      // 2^-13
+
+#define MAX_UNITS16 1024               // (row block, bank tile, column group) units per node: K up to 49 152 at P <= 272
+struct Tiled16Lds {
+    float tmax0[MAX_UNITS16];      // unsuppressed unit maxima (first sibling's sweep)
+    float tcur[MAX_UNITS16];       // unit maxima of the current sibling's sweep (-inf = skipped)
+    int sib_pos[CSC_MAX_CONNECTIONS], sib_atom[CSC_MAX_CONNECTIONS];
+    int gs0[NG], gs1[NG];          // slab range of each column group of the current tile
+    int cur_tile;                  // bank tile whose metadata sl->perm / sl->masks / gs0 / gs1 hold (-1 = none)
+    short order[MAX_UNITS16];      // units by descending unsuppressed maximum (the later siblings' sweep order)
+};
+
+// group-slab s of group g -> one ring slot: 6 KiB = 3 hi blocks + 3 lo blocks; every wave issues two copies (one
+// whole block, one half block), so "my copies of slab s have landed" is the same vmcnt on every wave
+__device__ __forceinline__ void stage_group16x3(const _Float16* hi_slab, const _Float16* lo_slab, _Float16* lslot, int g,
+                                                int wave, int lane) {
+    const _Float16* src = wave < NG ? hi_slab + (NG * g + wave) * BLKF : lo_slab + NG * g * BLKF;    // pieces 0..3
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + lane * 8), (lptr_t)(lslot + wave * BLKF), 16, 0, 0);
+    const int p = 4 + (wave >> 1), half = (wave & 1) * (BLKF / 2);                                  // pieces 4, 5 in halves
+    if (lane < 32)
+        __builtin_amdgcn_global_load_lds((gptr_t)(lo_slab + (NG * g + p - NG) * BLKF + half + lane * 8),
+                                         (lptr_t)(lslot + p * BLKF + half), 16, 0, 0);
+}
+
+// acc[mi][nj]: positions rowbase + 64 wave + 16 mi + ..., column tile 3 g + nj, over slabs [s0, s1) of the tile at
+// (hi, lo); REM: accr = the remainder row tile (positions rowbase + 256 + ...), column tile 3 g + wave (waves 0..2)
+template <bool REM>
+__device__ __forceinline__ void gemm16x3_group(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo, int g,
+                                               int s0, int s1, const _Float16* rh, const _Float16* rl, int R16T_CS,
+                                               int rowbase, _Float16* ring, f32x4 (&acc)[MT][NG], f32x4& accr) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NG; ++nj) acc[mi][nj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    accr = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // fragment (row tile mi, slab s) of this lane: elements row + 8 lq + 32 s ... + 7 of the window, row = rowbase +
+    // 64 wave + 16 mi + lr, i.e. one aligned 16-byte read of shifted copy row mod 8
+    const int aoff = (lr & 7) * R16T_CS + rowbase + 64 * wave + (lr & 8) + 8 * lq;
+    const int roff = (lr & 7) * R16T_CS + rowbase + CSC_TILE_ROWS + (lr & 8) + 8 * lq;
+    WAIT_VM(0);                                                      // nothing of ours in flight: the counts below hold
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (s0 + q < s1)
+            stage_group16x3(hi + (size_t)(s0 + q) * SLABF, lo + (size_t)(s0 + q) * SLABF, ring + q * TG_BLK, g, wave, lane);
+    f16x8 ah[2][MT], al[2][MT], arh[2], arl[2], bh[2][NG], bl[2][NG];
+#ifdef CSC_PHASE_PROF
+    unsigned t3acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t3last = T3_CLK();
+#endif
+    auto load_a = [&](auto setc, int s) {
+        constexpr int set = decltype(setc)::value;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            ah[set][mi] = *reinterpret_cast<const f16x8*>(rh + aoff + 16 * mi + 32 * s);
+            al[set][mi] = *reinterpret_cast<const f16x8*>(rl + aoff + 16 * mi + 32 * s);
+        }
+        if (REM) {
+            arh[set] = *reinterpret_cast<const f16x8*>(rh + roff + 32 * s);
+            arl[set] = *reinterpret_cast<const f16x8*>(rl + roff + 32 * s);
+        }
+    };
+    auto load_b = [&](auto setc, int slot) {
+        constexpr int set = decltype(setc)::value;
+        const _Float16* sb = ring + slot * TG_BLK + lane * 8;
+#pragma unroll
+        for (int nj = 0; nj < NG; ++nj) {
+            bh[set][nj] = *reinterpret_cast<const f16x8*>(sb + nj * BLKF);
+            bl[set][nj] = *reinterpret_cast<const f16x8*>(sb + (NG + nj) * BLKF);
+        }
+    };
+#define T3_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, C, 0, 0, 0)
+    // the remainder tile's three MFMAs use the B fragments of column tile `wave` (waves 0..2; wave 3 multiplies tile 2
+    // again and its result is masked): picked with uniform bit masks -- a branch would split the scheduling region of a
+    // slab, and indexing the fragment array with the wave number would put the array in scratch
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned m0 = wave == 0 ? ~0u : 0u, m1 = wave == 1 ? ~0u : 0u, m2 = wave >= 2 ? ~0u : 0u;
+    auto pick = [&](const f16x8 (&bv)[NG]) -> f16x8 {
+        const u32x4 r = (__builtin_bit_cast(u32x4, bv[0]) & m0) | (__builtin_bit_cast(u32x4, bv[1]) & m1) |
+                        (__builtin_bit_cast(u32x4, bv[2]) & m2);
+        return __builtin_bit_cast(f16x8, r);
+    };
+    // One slab.  Its fragments were requested during the slab before, so the first twelve MFMAs go out at once and
+    // execute while the wave waits at the barrier; behind the barrier slab s + 1 has landed for everybody (its
+    // fragments can be requested) and the slot slab s - 1 was read from is free for the copy of slab s + 3.  The copies
+    // and the fragment requests sit between the blocks of MFMAs, in the shadow of the matrix pipe.
+    auto body = [&](auto setc, int s, int slot) {
+        constexpr int set = decltype(setc)::value;
+        __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));   // lgkmcnt(0)
+        T3_STAMP(0);
+        f16x8 bhw, blw;
+        if (REM) { bhw = pick(bh[set]); blw = pick(bl[set]); }
+#pragma unroll
+        for (int nj = 0; nj < NG; ++nj)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) T3_MFMA(ah[set][mi], bh[set][nj], acc[mi][nj]);
+        if (REM) T3_MFMA(arh[set], bhw, accr);
+        __builtin_amdgcn_sched_barrier(0);
+        T3_STAMP(1);
+        if (s + 2 < s1) WAIT_VM(2); else WAIT_VM(0);
+        T3_STAMP(2);
+        __builtin_amdgcn_s_barrier();
+        T3_STAMP(3);
+        if (s + 3 < s1)
+            stage_group16x3(hi + (size_t)(s + 3) * SLABF, lo + (size_t)(s + 3) * SLABF, ring + ((slot + 3) & (TRING - 1)) * TG_BLK,
+                            g, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        T3_STAMP(4);
+        // the fragments of the next slab (the last slab re-reads itself: no branch inside the scheduling region) are
+        // requested one by one in the shadows of the remaining MFMAs
+        {
+            const int sn = s + 1 < s1 ? s + 1 : s;
+            load_a(std::integral_constant<int, 1 - set>{}, sn);
+            load_b(std::integral_constant<int, 1 - set>{}, (slot + (s + 1 < s1 ? 1 : 0)) & (TRING - 1));
+        }
+#pragma unroll
+        for (int nj = 0; nj < NG; ++nj)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) T3_MFMA(ah[set][mi], bl[set][nj], acc[mi][nj]);
+        if (REM) T3_MFMA(arh[set], blw, accr);
+#pragma unroll
+        for (int nj = 0; nj < NG; ++nj)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) T3_MFMA(al[set][mi], bh[set][nj], acc[mi][nj]);
+        if (REM) T3_MFMA(arl[set], bhw, accr);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one LDS read
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        T3_STAMP(7);
+    };
+    if (s0 < s1) {
+        // the group's first slab: its A fragments now, its B fragments behind the barrier that says it has landed
+        load_a(std::integral_constant<int, 0>{}, s0);
+        const int later = min(2, s1 - 1 - s0);
+        if (later == 2) WAIT_VM(4); else if (later == 1) WAIT_VM(2); else WAIT_VM(0);
+        __builtin_amdgcn_s_barrier();
+        load_b(std::integral_constant<int, 0>{}, 0);
+    }
+    int slot = 0;
+    for (int s = s0; s < s1; s += 2) {
+        body(std::integral_constant<int, 0>{}, s, slot);
+        if (s + 1 < s1) body(std::integral_constant<int, 1>{}, s + 1, (slot + 1) & (TRING - 1));
+        slot = (slot + 2) & (TRING - 1);
+    }
+#undef T3_MFMA
+#ifdef CSC_PHASE_PROF
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_prof[8 + i][blockIdx.x % PROF_BUCKETS], (unsigned long long)t3acc[i]);
+        atomicAdd(&g_prof[7][blockIdx.x % PROF_BUCKETS], (unsigned long long)(s1 - s0));
+    }
+#endif
+    __syncthreads();
+}
+
+// masking of the entries outside the matrix + suppression by the first t siblings (bits from the similarity table);
+// returns the lane's maximum over its unsuppressed entries (remainder tile included), lane_supp = it holds a
+// suppressed one
+template <bool REM>
+__device__ __forceinline__ float group16x3_finish(const LevelArgs& a, const NodeLds* sl, const Tiled16Lds* tl, int g, int t,
+                                                  int rowbase, int (&permv)[NG], int& permr, f32x4 (&acc)[MT][NG],
+                                                  f32x4& accr, bool& lane_supp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int K = a.K, P = a.P, W = a.W;
+    const int prow = rowbase + 64 * wave + 4 * lq;
+    const int rrow = rowbase + CSC_TILE_ROWS + 4 * lq;
+#pragma unroll
+    for (int nj = 0; nj < NG; ++nj) permv[nj] = sl->perm[16 * (NG * g + nj) + lr];
+    permr = wave < NG ? sl->perm[16 * (NG * g + wave) + lr] : -1;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+        if (rowbase + 64 * wave + 16 * mi + 15 >= P) {               // wave-uniform
+#pragma unroll
+            for (int nj = 0; nj < NG; ++nj)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    if (prow + 16 * mi + rg >= P) acc[mi][nj][rg] = -INFINITY;
+        }
+#pragma unroll
+    for (int nj = 0; nj < NG; ++nj)
+        if (permv[nj] < 0) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) acc[mi][nj] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+    if (REM) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+            if (permr < 0 || rrow + rg >= P) accr[rg] = -INFINITY;
+    } else {
+        accr = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    }
+    lane_supp = false;
+    for (int q = 0; q < t; ++q) {
+        const uint32_t* srow = a.sim_bits + (size_t)tl->sib_atom[q] * K * W;
+        {
+            const int dpb = prow - tl->sib_pos[q] + P - 1;           // bit index of (mi, rg) = (0, 0); >= 0
+            const int w0 = dpb >> 5, b0 = dpb & 31;
+#pragma unroll
+            for (int nj = 0; nj < NG; ++nj) {
+                const uint32_t* row = srow + (size_t)max(permv[nj], 0) * W;
+                const uint32_t wd0 = row[min(w0, W - 1)], wd1 = row[min(w0 + 1, W - 1)], wd2 = row[min(w0 + 2, W - 1)];
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int off = b0 + 16 * mi + rg;           // < 32 + 52
+                        const uint32_t wd = off < 32 ? wd0 : (off < 64 ? wd1 : wd2);
+                        const bool hit = ((wd >> (off & 31)) & 1u) && acc[mi][nj][rg] > -INFINITY;
+                        acc[mi][nj][rg] = hit ? __uint_as_float(SUPP_BITS) : acc[mi][nj][rg];
+                        lane_supp |= hit;
+                    }
+            }
+        }
+        if (REM && permr >= 0) {
+            const int dpb = rrow - tl->sib_pos[q] + P - 1;
+            const int w0 = dpb >> 5, b0 = dpb & 31;
+            const uint32_t* row = srow + (size_t)permr * W;
+            const uint32_t wd0 = row[min(w0, W - 1)], wd1 = row[min(w0 + 1, W - 1)];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int off = b0 + rg;                             // < 32 + 4
+                const uint32_t wd = off < 32 ? wd0 : wd1;
+                const bool hit = ((wd >> (off & 31)) & 1u) && accr[rg] > -INFINITY;
+                accr[rg] = hit ? __uint_as_float(SUPP_BITS) : accr[rg];
+                lane_supp |= hit;
+            }
+        }
+    }
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NG; ++nj)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) lmax = fmaxf(lmax, acc[mi][nj][rg]);
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) lmax = fmaxf(lmax, accr[rg]);
+    return lmax;
+}
+
+__global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArgs a) {
+    extern __shared__ double lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int N = a.N, K = a.K, L = a.L, P = a.P, d = a.depth;
+    const int ntile = (K + CSC_TILE_COLS - 1) / CSC_TILE_COLS;
+    const int nslab = (L + SLAB - 1) / SLAB;
+    // row blocks of 256 positions; a last block of at most 16 positions rides along with the block before it
+    const int nrb_all = (P + CSC_TILE_ROWS - 1) / CSC_TILE_ROWS;
+    const bool rem = nrb_all > 1 && (P - (nrb_all - 1) * CSC_TILE_ROWS) <= 16;
+    const int nrb = rem ? nrb_all - 1 : nrb_all;
+    const int nunits = nrb * ntile * NG;
+    const int R16T_CS = r16t_stride(P, nslab * SLAB);
+
+    // ---- LDS carve-up: r64 [Npad] | rh, rl [8][R16T_CS] halves each | ring [TRING][TG_BLK] halves | NodeLds | Tiled16Lds
+    const int Npad = (N + 3) & ~3;
+    double* r64 = lds_raw;
+    _Float16* rh = reinterpret_cast<_Float16*>(r64 + Npad);
+    _Float16* rl = rh + R16_COPIES * R16T_CS;
+    _Float16* ring = rl + R16_COPIES * R16T_CS;
+    NodeLds* sl = reinterpret_cast<NodeLds*>(ring + TRING * TG_BLK);
+    PROF_INIT(0);
+    Tiled16Lds* tl = reinterpret_cast<Tiled16Lds*>(sl + 1);
+
+    const int Fd = a.ts.F[d], Fc = a.ts.F[d + 1];
+    size_t s;
+    int j;
+    node_of_block(Fd, s, j);
+    const int stride = a.ts.pw[d];
+    int nch = 0;
+    for (int r = 0; r < a.connections; ++r) {
+        if ((long long)j + (long long)r * stride < Fc) ++nch; else break;
+    }
+    const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
+    double rnorm2, first[4];
+    node_prologue(a, sl, r64, nullptr, Npad, 0, rin, s, j, rnorm2, first, d);
+    uint8_t* flag = a.flags + s * Fd + j;
+    if (tid == 0) *flag = 0;
+    const float am2 = *a.amax2, am = sqrtf(am2);
+    // NaN / Inf / extreme scales: fp32 (workgroup-uniform)
+    if (!(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 1e-30 && rnorm2 < 1e30)) {
+        if (tid == 0) { *flag = 1; if (a.stats) atomicAdd(&a.stats[3], 1); }
+        return;
+    }
+    const float band = 2.f * ((EPS3_ACC + 9.5367431640625e-07f) * am + 1.862645149230957e-09f * sqrtf((float)L) * (1.f + am));
+    const float unscale = 1.f / (64.f * split_scale(am2));           // accumulators -> units of ||r||
+    {
+        // the residual as a two-term fp16 number, scaled to norm 64, in 8 shifted copies each
+        const double sc = 64.0 / sqrt(rnorm2);
+        for (int i = tid; i < R16_COPIES * R16T_CS; i += WG) {
+            const int c = i / R16T_CS, e = i - c * R16T_CS + c;
+            const double x = e < N ? r64[e] * sc : 0.0;
+            const _Float16 h = (_Float16)x;
+            rh[i] = h;
+            rl[i] = (_Float16)(x - (double)h);
+        }
+    }
+    __syncthreads();
+    const _Float16* hi_all = reinterpret_cast<const _Float16*>(a.bank16);      // scaled tiles: hi, then lo
+    const _Float16* lo_all = hi_all + (size_t)ntile * nslab * SLABF;
+
+    f32x4 acc[MT][NG], accr;
+    int permv[NG], permr;
+    // one unit: GEMM + masks + suppression; the unscaled lane maximum
+    auto unit = [&](int u, int t, bool& lane_supp, int& rowbase) -> float {
+        const int g = u % NG, tile = (u / NG) % ntile, rb = u / (NG * ntile);
+        const bool with_rem = rem && rb == nrb - 1;                  // uniform
+        rowbase = rb * CSC_TILE_ROWS;
+        const _Float16* th = hi_all + (size_t)tile * nslab * SLABF;
+        const _Float16* tlo = lo_all + (size_t)tile * nslab * SLABF;
+        float lmax;
+        if (with_rem) {
+            gemm16x3_group<true>(th, tlo, g, tl->gs0[g], tl->gs1[g], rh, rl, R16T_CS, rowbase, ring, acc, accr);
+            lmax = group16x3_finish<true>(a, sl, tl, g, t, rowbase, permv, permr, acc, accr, lane_supp);
+        } else {
+            gemm16x3_group<false>(th, tlo, g, tl->gs0[g], tl->gs1[g], rh, rl, R16T_CS, rowbase, ring, acc, accr);
+            lmax = group16x3_finish<false>(a, sl, tl, g, t, rowbase, permv, permr, acc, accr, lane_supp);
+        }
+        return lmax;
+    };
+    // per bank tile: metadata -> LDS, slab range of each column group (outside it the group's blocks are zero padding)
+    if (tid == 0) tl->cur_tile = -1;
+    auto tile_setup = [&](int tile) {
+        __syncthreads();                                              // everybody is done with the tile before
+        if (tl->cur_tile == tile) return;                             // uniform
+        load_tile_meta(a, sl, tile);
+        if (tid < NG) {
+            int lo = nslab, hi = 0;
+            for (int q = 0; q < nslab; ++q)
+                if ((sl->masks[q] >> (NG * tid)) & 7u) { lo = min(lo, q); hi = q + 1; }
+            tl->gs0[tid] = min(lo, hi);
+            tl->gs1[tid] = hi;
+        }
+        if (tid == 0) tl->cur_tile = tile;
+        __syncthreads();
+    };
+    // one unit of sweep 1: its maximum -> tcur (and tmax0 for the first sibling), running maximum
+    auto sweep_unit = [&](int u, int t, float& gmax) {
+        tile_setup((u / NG) % ntile);
+        bool lane_supp;
+        int rowbase;
+        const float lmax = unit(u, t, lane_supp, rowbase);
+        const float bv = wave_max(lane_supp ? fmaxf(lmax, 0.f) : lmax);
+        if (lane == 63) sl->wmax[wave] = bv;
+        __syncthreads();
+        const float m = fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
+        if (tid == 0) {
+            tl->tcur[u] = m;
+            if (t == 0) tl->tmax0[u] = m;
+        }
+        gmax = fmaxf(gmax, m);
+    };
+
+    for (int t = 0; t < nch; ++t) {
+        // ---- sweep 1: unit maxima (in accumulator units; the band is scaled to match) ----------------------
+        const float bandu = band / unscale;
+        float gmax = -INFINITY;                                       // workgroup-uniform
+        if (t == 0) {
+            for (int u = 0; u < nunits; ++u) sweep_unit(u, 0, gmax);
+            if (nch > 1) {
+                // the later siblings visit the units by descending unsuppressed maximum: the first few hold the new
+                // maximum, and once a unit cannot reach the band of the running maximum no later one can
+                __syncthreads();
+                for (int u = tid; u < nunits; u += WG) {
+                    const float v = tl->tmax0[u];
+                    int rank = 0;
+                    for (int w = 0; w < nunits; ++w) {
+                        const float x = tl->tmax0[w];
+                        rank += (x > v || (x == v && w < u)) ? 1 : 0;
+                    }
+                    tl->order[rank] = (short)u;
+                }
+            }
+        } else {
+            for (int u = tid; u < nunits; u += WG) tl->tcur[u] = -INFINITY;
+            __syncthreads();
+            for (int i = 0; i < nunits; ++i) {
+                const int u = tl->order[i];
+                if (fmaxf(tl->tmax0[u], 0.f) < gmax - bandu) break;   // cannot reach the band, nor can the rest (uniform)
+                sweep_unit(u, t, gmax);
+            }
+        }
+        __syncthreads();
+        // ---- sweep 2: candidates from the units that reach the band --------------------------------------
+        const float tau = gmax - bandu;
+        // the value 0 of suppressed entries inside the band, or no finite maximum: the fp32 kernel decides
+        if ((0.f >= tau && t > 0) || !(gmax > -INFINITY) || !(gmax < INFINITY)) {
+            if (tid == 0) { *flag = 1; if (a.stats) atomicAdd(&a.stats[3], 1); }
+            return;
+        }
+        if (tid == 0) sl->cand_cnt = 0;
+        __syncthreads();
+        for (int u = 0; u < nunits; ++u) {
+            if (!(tl->tcur[u] >= tau)) continue;                      // uniform
+            const int g = u % NG;
+            tile_setup((u / NG) % ntile);
+            bool lane_supp;
+            int rowbase;
+            const float lmax = unit(u, t, lane_supp, rowbase);
+            if (lmax >= tau) {
+                const int rowK = (rowbase + 64 * wave + 4 * lq) * K;
+                uint32_t mk[2] = {0u, 0u};
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                        for (int nj = 0; nj < NG; ++nj) {
+                            const int e = (4 * mi + rg) * NG + nj;
+                            mk[e >> 5] |= (acc[mi][nj][rg] >= tau) ? (1u << (e & 31)) : 0u;
+                        }
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    uint32_t mm = mk[w];
+                    while (mm) {
+                        const int e = 32 * w + __builtin_ctz(mm);
+                        mm &= mm - 1;
+                        const int r = e / NG, nj = e - r * NG;
+                        const int idx = rowK + (16 * (r >> 2) + (r & 3)) * K + sl->perm[16 * (NG * g + nj) + lr];
+                        const int slot = atomicAdd(&sl->cand_cnt, 1);
+                        if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
+                    }
+                }
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    if (accr[rg] >= tau) {
+                        const int idx = (rowbase + CSC_TILE_ROWS + 4 * lq + rg) * K + permr;
+                        const int slot = atomicAdd(&sl->cand_cnt, 1);
+                        if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
+                    }
+            }
+        }
+        __syncthreads();
+        const int ncand_raw = sl->cand_cnt;
+        if (ncand_raw > CAND_CAP) {                                   // too many entries in the band: fp32
+            if (tid == 0) { *flag = 1; if (a.stats) atomicAdd(&a.stats[3], 1); }
+            return;
+        }
+        rescore_and_choose(a, sl, r64, ncand_raw, false, d);
+        const int jc = j + t * stride;
+        const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
+        if (tid == 0) { tl->sib_pos[t] = sl->sup_pos[d]; tl->sib_atom[t] = sl->sup_atom[d]; }
+        child_solve_and_write(a, sl, r64, s, jc, cid, d, a.resid_out, false);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // batched atom matching (API parity: utils.computeMaxTruePositives)
 // ------------------------------------------------------------------------------------------------
 // One wave per problem.  cost[i][j] = 0 where |pos_i - pos_j| <= pos_thr and |<a_i @ pos_i, a_j @ pos_j>|
@@ -2107,6 +2626,105 @@ __global__ __launch_bounds__(64) void match_kernel(const double* __restrict__ ba
             (void)prev_owner_j;
         }
         tp[m] = matched;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// on-device constrained signal generator (benchmark input: src/csc/dictionary.py:271-324, 326-365)
+// ------------------------------------------------------------------------------------------------
+// One workgroup per signal: unit-amplitude atoms drawn uniformly (atom, position), a draw rejected when it lies
+// closer than pos_thr samples to, or correlates more than corr_thr with, an atom already placed (:302-311); white
+// Gaussian noise whose variance is var(clean[|clean| > 1e-3]) / 10^(snr/10) (:318-322).  Random numbers: Philox-4x32-10,
+// counter = (draw or sample index, signal index, stream), key = seed -- the result depends on (seed, signal index)
+// only, not on the launch.  The reference draws from NumPy's global Mersenne Twister, which a device generator cannot
+// reproduce: parity here is statistical (the constraints, the SNR), not the stream.
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                           uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+#define GEN_MAX_TRIALS 65536
+__global__ __launch_bounds__(WG) void generate_kernel(const double* __restrict__ bank64, const double* __restrict__ anorm2,
+                                                      int K, int L, int N, int P, const int32_t* __restrict__ sparsity,
+                                                      const double* __restrict__ snr_db, int kmax, double pos_thr,
+                                                      double corr_thr, uint64_t seed, uint64_t first_index,
+                                                      double* __restrict__ signals, int32_t* __restrict__ truth,
+                                                      int32_t* __restrict__ fail) {
+    __shared__ int kept_pos[KMAX], kept_atom[KMAX];
+    __shared__ int verdict;
+    __shared__ double red[3][WG / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t s = blockIdx.x;
+    const uint64_t gid = first_index + s;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const int want = min(max(sparsity[s], 0), min(kmax, KMAX));
+    int have = 0;
+    if (tid == 0) verdict = 0;
+    __syncthreads();
+    for (uint32_t trial = 0; have < want && trial < GEN_MAX_TRIALS; ++trial) {
+        uint32_t r[4];
+        philox4x32(trial, (uint32_t)gid, (uint32_t)(gid >> 32), 0u, k0, k1, r);          // stream 0: placements
+        const int atom = (int)(((uint64_t)r[0] * (uint64_t)K) >> 32), pos = (int)(((uint64_t)r[1] * (uint64_t)P) >> 32);
+        bool near = false;
+        for (int q = 0; q < have; ++q) near |= fabs((double)(pos - kept_pos[q])) < pos_thr;
+        if (near) continue;                                            // uniform: every thread drew the same numbers
+        for (int q = wave; q < have; q += WG / 64) {
+            const int ka = kept_atom[q], dp = pos - kept_pos[q];      // a_q index = i + dp
+            double v = dot_range<64>(bank64 + (size_t)atom * L, bank64 + (size_t)ka * L + dp, max(0, -dp), min(L, L - dp), lane);
+            v = wave_sum(v);
+            if (lane == 63 && v / sqrt(anorm2[atom] * anorm2[ka]) > corr_thr) atomicOr(&verdict, 1);
+        }
+        __syncthreads();
+        const bool rejected = verdict != 0;
+        __syncthreads();
+        if (tid == 0) {
+            verdict = 0;
+            if (!rejected) { kept_pos[have] = pos; kept_atom[have] = atom; }
+        }
+        __syncthreads();
+        if (!rejected) ++have;
+    }
+    if (tid == 0 && fail) fail[s] = have < want ? 1 : 0;
+    if (tid < kmax) {
+        truth[(s * kmax + tid) * 2] = tid < have ? kept_pos[tid] : -1;
+        truth[(s * kmax + tid) * 2 + 1] = tid < have ? kept_atom[tid] : -1;
+    }
+    // clean signal, statistics of its active samples
+    double cnt = 0.0, sum = 0.0, sq = 0.0;
+    for (int n = tid; n < N; n += WG) {
+        double c = 0.0;
+        for (int q = 0; q < have; ++q) {
+            const int o = n - kept_pos[q];
+            if ((unsigned)o < (unsigned)L) c += bank64[(size_t)kept_atom[q] * L + o];
+        }
+        if (fabs(c) > 1e-3) { cnt += 1.0; sum += c; sq = fma(c, c, sq); }
+    }
+    cnt = wave_sum(cnt); sum = wave_sum(sum); sq = wave_sum(sq);
+    if (lane == 63) { red[0][wave] = cnt; red[1][wave] = sum; red[2][wave] = sq; }
+    __syncthreads();
+    double tc = 0.0, ts = 0.0, tq = 0.0;
+    for (int w = 0; w < WG / 64; ++w) { tc += red[0][w]; ts += red[1][w]; tq += red[2][w]; }
+    const double mean = tc > 0.0 ? ts / tc : 0.0;
+    const double var = tc > 0.0 ? fmax(tq / tc - mean * mean, 0.0) : 0.0;             // np.var: population variance
+    const double sigma = sqrt(var / pow(10.0, snr_db[s] / 10.0));
+    for (int n = tid; n < N; n += WG) {
+        double c = 0.0;
+        for (int q = 0; q < have; ++q) {
+            const int o = n - kept_pos[q];
+            if ((unsigned)o < (unsigned)L) c += bank64[(size_t)kept_atom[q] * L + o];
+        }
+        uint32_t r[4];
+        philox4x32((uint32_t)n, (uint32_t)gid, (uint32_t)(gid >> 32), 1u, k0, k1, r);      // stream 1: noise
+        const double u1 = ((double)r[0] * 4294967296.0 + (double)r[1] + 0.5) * 5.421010862427522e-20;   // (0, 1)
+        const double u2 = ((double)r[2] * 4294967296.0 + (double)r[3] + 0.5) * 5.421010862427522e-20;
+        const double z = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        signals[s * (size_t)N + n] = c + sigma * z;
     }
 }
 
@@ -2175,7 +2793,8 @@ static int ceil8(int v) { return (v + 7) & ~7; }
 static int n_tiles(int K) { return (K + CSC_TILE_COLS - 1) / CSC_TILE_COLS; }
 static int n_slabs(int L) { return (L + SLAB - 1) / SLAB; }
 static size_t tile_floats(int K, int L) { return (size_t)n_tiles(K) * n_slabs(L) * SLABF; }
-// packed bank buffer: [fp32 tiles][meta per tile][fp16 tiles][amax2 + spare (16 floats)][anorm2: K doubles]
+// packed bank buffer: [fp32 tiles][meta per tile][fp16 tiles][amax2 + spare (16 floats)][anorm2: K doubles, padded to an
+// even count][scaled fp16 tiles hi][scaled fp16 tiles lo]
 static size_t bank16_offset(int K, int L) { return tile_floats(K, L) + (size_t)n_tiles(K) * META_INTS; }
 static const _Float16* bank_tiles16(const float* d_bank32t, int K, int L) {
     return reinterpret_cast<const _Float16*>(d_bank32t + bank16_offset(K, L));
@@ -2185,6 +2804,11 @@ static const float* bank_amax2(const float* d_bank32t, int K, int L) {
 }
 static const double* bank_anorm2(const float* d_bank32t, int K, int L) {
     return reinterpret_cast<const double*>(bank_amax2(d_bank32t, K, L) + 16);
+}
+// behind anorm2: the scaled two-term fp16 tiles (hi, lo) of the tiled kernel's filter
+static const _Float16* bank_tiles16s(const float* d_bank32t, int K, int L, int lo) {
+    const double* end = bank_anorm2(d_bank32t, K, L) + K + (K & 1);          // 16-byte aligned
+    return reinterpret_cast<const _Float16*>(end) + (lo ? tile_floats(K, L) : 0);
 }
 static const int32_t* bank_meta(const float* d_bank32t, int K, int L) {
     return reinterpret_cast<const int32_t*>(d_bank32t + tile_floats(K, L));
@@ -2245,7 +2869,7 @@ const char* csc_last_error(void) { return g_err; }
 
 size_t csc_bank32_elems(int K, int L) {
     if (K <= 0 || L <= 0) return 0;
-    return bank16_offset(K, L) + tile_floats(K, L) / 2 + 16 + 2 * (size_t)K;
+    return bank16_offset(K, L) + tile_floats(K, L) / 2 + 16 + 2 * (size_t)(K + (K & 1)) + tile_floats(K, L);
 }
 
 int csc_sim_words(int N, int L) {
@@ -2267,13 +2891,18 @@ int csc_bank_pack(const double* d_bank64, int K, int L, float* d_bank32t, void* 
     hipLaunchKernelGGL(bank_rank_kernel, dim3((K + 255) / 256), dim3(256), 0, st, keys, K, npad, meta);
     hipLaunchKernelGGL(bank_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_bank64, K, L,
                        nslab, meta, d_bank32t, total);
-    hipLaunchKernelGGL(bank_mask_kernel, dim3(nslab, ntile), dim3(256), 0, st, d_bank32t, nslab, meta);
+    hipLaunchKernelGGL(bank_mask_kernel, dim3(MAX_SLABS, ntile), dim3(256), 0, st, d_bank32t, nslab, meta);
     hipLaunchKernelGGL(bank_pack16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_bank64, K, L,
                        nslab, meta, const_cast<_Float16*>(bank_tiles16(d_bank32t, K, L)), total);
     float* amax2 = const_cast<float*>(bank_amax2(d_bank32t, K, L));
     if (hipMemsetAsync(amax2, 0, 16 * sizeof(float), st) != hipSuccess) FAIL(-1, "csc_bank_pack: hipMemsetAsync failed");
+    if ((K & 1) && hipMemsetAsync(const_cast<double*>(bank_anorm2(d_bank32t, K, L)) + K, 0, sizeof(double), st) != hipSuccess)
+        FAIL(-1, "csc_bank_pack: hipMemsetAsync failed");                // the pad behind anorm2: every byte of the image is defined
     hipLaunchKernelGGL(bank_norm_kernel, dim3(K), dim3(64), 0, st, d_bank64, K, L, amax2,
                        const_cast<double*>(bank_anorm2(d_bank32t, K, L)));
+    hipLaunchKernelGGL(bank_pack16s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_bank64, K, L,
+                       nslab, meta, amax2, const_cast<_Float16*>(bank_tiles16s(d_bank32t, K, L, 0)),
+                       const_cast<_Float16*>(bank_tiles16s(d_bank32t, K, L, 1)), total);
     return launch_status("bank_pack kernels");
 }
 
@@ -2376,7 +3005,15 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
     if (tiled) lds += (size_t)(nrb - 1) * CSC_TILE_ROWS * 4 + sizeof(TiledLds);
     if (lds > 150 * 1024) FAIL(-8, "signal too long for the LDS-resident node kernel (%zu B)", lds);
     if (!tiled && (size_t)K * (W + 1) * 4 > 2 * SLABF * 4) FAIL(-8, "similarity row does not fit the slab buffer");
+    // dictionaries beyond one register tile: the fp16 three-product filter in front of the fp32 kernel (needs the flag
+    // buffer; its accumulation bound 3 L 2^-24 <= 2^-13 holds up to L = 682)
+    const size_t lds16 = (size_t)ceil4(N) * 8 + 2 * (size_t)R16_COPIES * r16t_stride(P, Lp) * 2 + (size_t)TRING * TG_BLK * 2 +
+                         sizeof(NodeLds) + sizeof(Tiled16Lds);
+    const bool tiled16 = tiled && !(flags & CSC_FLAG_FP32_ONLY) && node_flags && mode == 0 && L <= 682 &&
+                         lds16 <= 80 * 1024 && (long long)n_tiles(K) * nrb * NG <= MAX_UNITS16;
     clear_stale_error();
+    if (tiled16) hipFuncSetAttribute((const void*)mmp_level_tiled16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds16);
     hipFuncSetAttribute(tiled ? (const void*)mmp_level_tiled_kernel : (const void*)mmp_level_kernel,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (!tiled) hipFuncSetAttribute((const void*)mmp_level_followup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2404,7 +3041,14 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         const int span = timer_begin(st, d);
         a.flags = nullptr; a.S = S; a.signals = d_signals; a.ws[0] = ws[0]; a.ws[1] = ws[1];
         bool chain = false;
-        if (tiled) {
+        if (tiled16) {
+            // the three-product fp16 filter takes the level; the fp32 kernel behind it redoes the flagged nodes
+            a.flags = node_flags;
+            a.bank16 = bank_tiles16s(d_bank32t, K, L, 0);
+            hipLaunchKernelGGL(mmp_level_tiled16_kernel, dim3((unsigned)grid), dim3(WG), lds16, st, a);
+            a.bank16 = nullptr;
+            hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
+        } else if (tiled) {
             hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
         } else if (lean && (connections == 1 || ts.pw[d] >= ts.F[d + 1])) {
             // every node of this level has one child (node j's second child j + pw[d] falls outside F[d + 1]), and
@@ -2490,6 +3134,23 @@ int csc_match_batch(const double* d_bank64, int K, int L, const int32_t* d_true,
     hipLaunchKernelGGL(match_kernel, dim3((unsigned)M), dim3(64), 0, (hipStream_t)stream, d_bank64, K, L, d_true, kt,
                        d_approx, ka, pos_err_threshold, corr_err_threshold, d_tp);
     return launch_status("match_kernel");
+}
+
+int csc_generate_signals(const float* d_bank32t, const double* d_bank64, int K, int L, int N, int S,
+                         const int32_t* d_sparsity, const double* d_snr_db, int kmax, double pos_err_threshold,
+                         double corr_err_threshold, uint64_t seed, uint64_t first_index, double* d_signals,
+                         int32_t* d_truth, int32_t* d_fail, void* stream) {
+    const int P = N - L + 1;
+    if (!d_bank32t || !d_bank64 || !d_sparsity || !d_snr_db || !d_signals || !d_truth || K <= 0 || L <= 0 || S < 0)
+        FAIL(-1, "csc_generate_signals: bad arguments");
+    if (P <= 0) FAIL(-6, "signal length %d shorter than atom length %d", N, L);
+    if (kmax < 1 || kmax > KMAX) FAIL(-2, "kmax %d outside [1, %d]", kmax, KMAX);
+    if (S == 0) return 0;
+    clear_stale_error();
+    hipLaunchKernelGGL(generate_kernel, dim3((unsigned)S), dim3(WG), 0, (hipStream_t)stream, d_bank64,
+                       bank_anorm2(d_bank32t, K, L), K, L, N, P, d_sparsity, d_snr_db, kmax, pos_err_threshold,
+                       corr_err_threshold, seed, first_index, d_signals, d_truth, d_fail);
+    return launch_status("generate_kernel");
 }
 
 int csc_project_batch(const double* d_bank64, int K, int L, const double* d_signals, int S, int N,

@@ -326,6 +326,28 @@ class CSCDictionary:
                          {"posErrThreshold": pos_err_threshold, "corrErrThreshold": corr_err_threshold},
                          output_filename)
 
+    def generateConstrainedSignalsDevice(self, batch_size: int, signal_length: int, sparsity_levels: List[int],
+                                         snr_levels: List[float], pos_err_threshold: float,
+                                         corr_err_threshold: float, seed: int = 0, first_index: int = 0):
+        """generateConstrainedSignalsDB's batch (reference :326-365: ``batch_size`` signals per (snr, sparsity) in
+        itertools.product(snr_levels, sparsity_levels) order, ids consecutive) generated ON THE GPU and left
+        there: returns {'signals': float64 tensor [S, N] on the device, 'ids', 'snr', 'sparsity': arrays [S],
+        'truth': int32 [S, kmax, 2] (pos, atom) in placement order, -1 padded}.  Same placement constraints and
+        noise rule as generateConstrainedTestSignal (:271-324); the random stream is Philox (seed, signal id), not
+        NumPy's global generator, so signals are not the ones the host generator would draw."""
+        snr, sp = [], []
+        for v, k in itertools.product(snr_levels, sparsity_levels):
+            snr += [v] * batch_size
+            sp += [k] * batch_size
+        sig, truth = self.device_bank().generate(sp, snr, signal_length, pos_err_threshold, corr_err_threshold,
+                                                 seed=seed, first_index=first_index)
+        return {"signals": sig, "ids": np.arange(first_index, first_index + len(sp)), "snr": np.asarray(snr),
+                "sparsity": np.asarray(sp, dtype=np.int32), "truth": truth}
+
+    def truthInfos(self, truth_row) -> List[dict]:
+        """[(pos, atom)] of the device generator -> the reference's atom dicts ({'x','b','y','s'})."""
+        return [self._info(p, k) for p, k in truth_row if p >= 0]
+
     def atomsDictPositionMatchingErrors(self, atoms_info: List[dict], recov_atoms_info: List[dict]) -> List[int]:
         """reference :367-378"""
         err = [[np.abs(t["x"] - r["x"]) for r in recov_atoms_info] for t in atoms_info]
@@ -697,6 +719,36 @@ class CSCDictionary:
         with open(output_filename, "w") as f:
             json.dump(results, f, indent=4, default=handle_non_serializable)
 
+    def _dump_sparvar_stream(self, header: dict, list_key: str, res, ids, snrs, delay, output_filename) -> bool:
+        """json.dump(dict(header, **{list_key: [sparVar entries]}), indent=4, default=handle_non_serializable) --
+        the SAME BYTES (reference :1148-1150) -- with the list written by the library's streaming writer straight
+        from the packed records (csc_sparvar_json_write, include/csc_hip.h) instead of through ~30 Python objects
+        per signal.  Returns False (nothing written) when an id / snr is not a plain int / float, so that the
+        caller can fall back to json.dump."""
+        import ctypes as C
+        from . import _lib
+        if not all(type(i) is int for i in ids) or not all(type(v) in (int, float) for v in snrs):
+            return False
+        if any(abs(i) >= 2 ** 63 for i in ids) or any(type(v) is int and abs(v) >= 2 ** 53 for v in snrs):
+            return False
+        S, K = len(res), res.max_sparsity
+        raw = np.ascontiguousarray(res.to_records("rec"))
+        ids_a = np.asarray(ids, dtype=np.int64)
+        snr_a = np.asarray(snrs, dtype=np.float64)
+        is_int = np.array([type(v) is int for v in snrs], dtype=np.uint8)
+        pb, py, ps = (np.array([a.params[k] for a in self.atoms], dtype=np.float64) for k in ("b", "y", "sigma"))
+        head = json.dumps(header, indent=4, default=handle_non_serializable)
+        assert head.endswith("\n}") and header
+        with open(output_filename, "w") as f:
+            f.write(head[:-2] + ",\n    " + json.dumps(list_key) + ": ")
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = _lib.lib().csc_sparvar_json_write(output_filename.encode(), 1, ptr(raw), S, K, res.connections,
+                                               ptr(ids_a), ptr(snr_a), ptr(is_int), float(delay), ptr(pb), ptr(py),
+                                               ptr(ps), len(self.atoms), 1, 1)
+        if rc != 0:
+            raise _lib.CscHipError("csc_sparvar_json_write failed: " + _lib.lib().csc_json_last_error().decode())
+        return True
+
     def ompPipelineFromDB(self, input_filename: str, output_filename: str, nb_cores: int, verbose=False):
         """reference :683-717 (``nb_cores`` is accepted and ignored: the batch runs on the GPU(s))"""
         data = self._load_db(input_filename)
@@ -765,6 +817,28 @@ class CSCDictionary:
         data = self._load_db(input_filename)
         if verbose:
             print(f"MMP-DF Pipeline from {input_filename} with {len(data['signals'])} signals")
+        header = {"source": input_filename, "date": get_today_date_str(), "algorithm": "Convolutional MMP-DF",
+                  "nbBranches": branches, "connections": connections, "dissimilarity": dissimilarity,
+                  "maxSparsityLevel": max_sparsity, "batchSize": data["batchSize"],
+                  "snrLevels": data["snrLevels"], "signalLength": data["signalLength"],
+                  "sparsityLevels": data["sparsityLevels"], "dictionary": str(self)}
+        sigs = data["signals"]
+        if len(sigs) and len({len(sd["signal"]) for sd in sigs}) == 1:
+            # one signal length (every DB the reference's generators write): one batched call, records -> JSON
+            # by the streaming writer; same bytes as the json.dump below
+            res, dt = self._batch(np.array([sd["signal"] for sd in sigs], dtype=np.float64), max_sparsity,
+                                  connections, branches, dissimilarity, sharded=True, fields="rec")
+            if res is None:
+                return
+            if self._dump_sparvar_stream(header, "mmp", res, [sd["id"] for sd in sigs], [sd["snr"] for sd in sigs],
+                                         dt, output_filename):
+                if verbose:
+                    print(f"MMP-DF SparVar Pipeline results saved in {output_filename}")
+                return
+            mmpdf_results = [{"id": sd["id"], "snr": sd["snr"], "results": self._sparvar_records(res, row, dt)}
+                             for row, sd in enumerate(sigs)]
+            self._dump(dict(header, mmp=mmpdf_results), output_filename)
+            return
         mmpdf_results = self._grouped(
             data["signals"], lambda sd: len(sd["signal"]),
             lambda k, sig: self._batch(sig, max_sparsity, connections, branches, dissimilarity, sharded=True,
@@ -828,6 +902,37 @@ class SparVarBatch:
         tp = d.device_bank().match_batch(np.repeat(truth, K, axis=0), approx.reshape(S * K, K, 2),
                                          pos_err_threshold, corr_err_threshold)
         return tp.reshape(S, K)
+
+    def save_json(self, path, ids=None, snrs=None, header=None, list_key="mmp"):
+        """The reference's sparVar result DB ({...header, 'mmp': [{'id','snr','results':[...]}]}, reference
+        dictionary.py:1132-1150) written by the streaming writer: ~1.5 KB of JSON per signal at millions of
+        per-sparsity records per second.  ``ids`` default to 0..S-1, ``snrs`` to 0."""
+        S = len(self)
+        ids = list(range(S)) if ids is None else [int(i) for i in ids]
+        snrs = [0] * S if snrs is None else list(snrs)
+        header = {"algorithm": "Convolutional MMP-DF", "dictionary": str(self.dictionary)} if header is None else header
+        if not self.dictionary._dump_sparvar_stream(header, list_key, self._res, ids, snrs, self.seconds_per_signal, path):
+            raise TypeError("ids must be ints and snrs ints or floats")
+
+    def save_records(self, path):
+        """Uncompressed binary form: ``path`` (.npy) holds the [S, (16 + 8 K) K] uint8 records exactly as the
+        device wrote them (K f64 mse | K x 2 i32 leaf | K x K x 2 i32 (pos, atom) per signal), ``path + '.json'``
+        the few numbers needed to read them back (SparVarBatch.load_records)."""
+        d = self.dictionary
+        np.save(path, self._res.to_records("rec"), allow_pickle=False)
+        with open(str(path) + ".json", "w") as f:
+            json.dump({"connections": int(self.connections), "branches": int(self._res.branches),
+                       "max_sparsity": int(self.max_sparsity), "seconds_per_signal": float(self.seconds_per_signal),
+                       "atom_b": [a.b for a in d.atoms], "atom_y": [a.y for a in d.atoms],
+                       "atom_sigma": [a.sigma for a in d.atoms]}, f)
+
+    @classmethod
+    def load_records(cls, dictionary, path):
+        with open(str(path) + ".json") as f:
+            meta = json.load(f)
+        raw = np.load(path if str(path).endswith(".npy") else str(path) + ".npy", allow_pickle=False)
+        return cls.from_records(dictionary, raw, meta["connections"], meta["branches"], meta["max_sparsity"],
+                                meta["seconds_per_signal"])
 
     def save_npz(self, path, **extra):
         """Compact binary form (~(16 + 8K) K bytes per signal instead of ~1.5 KB of JSON)."""

@@ -86,10 +86,11 @@ class BatchResult:
         """[S, rec_bytes] uint8: the per-signal fixed-size records that travel in the result gather
         (csc_amd.distributed.gather_rows)."""
         S = len(self)
-        cols = [np.ascontiguousarray(getattr(self, n)).reshape(S, -1).view(np.uint8)
-                for n, _, _ in self.field_specs(self.max_sparsity, self.connections, self.branches,
-                                                self.node_coef is not None, fields)]
-        return np.concatenate(cols, axis=1) if S else np.zeros((0, sum(c.shape[1] for c in cols)), np.uint8)
+        specs = self.field_specs(self.max_sparsity, self.connections, self.branches, self.node_coef is not None, fields)
+        if S == 0:
+            return np.zeros((0, sum(int(np.prod(shp)) * np.dtype(dt).itemsize for _, dt, shp in specs)), np.uint8)
+        return np.concatenate([np.ascontiguousarray(getattr(self, n)).reshape(S, -1).view(np.uint8)
+                               for n, _, _ in specs], axis=1)
 
     @classmethod
     def from_records(cls, raw, max_sparsity, connections, branches, want_coef, stats=None, fields="all"):
@@ -250,6 +251,35 @@ class DeviceBank:
                                              I, _ptr(ws), ws.numel() * 8, _ptr(pos), _ptr(atom), _ptr(mse),
                                              _ptr(mask), _ptr(stats), _stream(dev)), "csc_mp_batch")
         return pos.cpu().numpy(), atom.cpu().numpy(), mse.cpu().numpy(), mask.cpu().numpy()
+
+    # ---- on-device constrained signal generator (generateConstrainedSignalsDB) ---------------------------------
+    def generate(self, sparsities, snrs, signal_length, pos_err_threshold, corr_err_threshold, seed=0, first_index=0):
+        """-> (signals [S, N] float64 ON THE DEVICE, truth [S, kmax, 2] int32 host array of (pos, atom), -1 padded).
+        csc_generate_signals: Philox-keyed by (seed, first_index + s); raises if a signal could not be completed."""
+        sp = np.ascontiguousarray(sparsities, dtype=np.int32)
+        sn = np.ascontiguousarray(snrs, dtype=np.float64)
+        S, N = len(sp), int(signal_length)
+        if sn.shape != (S,):
+            raise ValueError("one snr per signal")
+        if N - self.L + 1 <= 0:
+            raise ValueError(f"signal length {N} shorter than atom length {self.L}")
+        kmax = max(1, int(sp.max()) if S else 1)
+        if kmax > _lib.MAX_SPARSITY or (S and sp.min() < 0):
+            raise ValueError(f"sparsity outside [0, {_lib.MAX_SPARSITY}]")
+        dev = self.device
+        with torch.cuda.device(dev):
+            d_sp, d_sn = torch.from_numpy(sp).to(dev), torch.from_numpy(sn).to(dev)
+            sig = torch.empty((S, N), dtype=torch.float64, device=dev)
+            truth = torch.empty((S, kmax, 2), dtype=torch.int32, device=dev)
+            fail = torch.zeros(max(S, 1), dtype=torch.int32, device=dev)
+            _lib.check(self.lib.csc_generate_signals(_ptr(self.bank32t), _ptr(self.bank64), self.K, self.L, N, S,
+                                                     _ptr(d_sp), _ptr(d_sn), kmax, float(pos_err_threshold),
+                                                     float(corr_err_threshold), int(seed), int(first_index), _ptr(sig),
+                                                     _ptr(truth), _ptr(fail), _stream(dev)), "csc_generate_signals")
+            if S and int(fail.sum().item()):
+                raise RuntimeError("csc_generate_signals: the placement constraints could not be met for "
+                                   f"{int(fail.sum().item())} signal(s)")
+        return sig, truth.cpu().numpy()
 
     # ---- batched MMP-DF ------------------------------------------------------------------------------
     def mmpdf_launch(self, sig: torch.Tensor, max_sparsity, connections, branches, dissimilarity,

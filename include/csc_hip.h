@@ -129,7 +129,7 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
  * a file-scope `static __device__` array of CSC_STATIC_SCRATCH_BYTES (64 MiB) that every GPU the library runs
  * on holds until the process ends.  The call allocates and frees nothing (no hipMalloc / hipFree, no library
  * allocator); a batch whose csc_mmpdf_workspace_bytes(...) exceeds the array is refused with -10 (config 2:
- * up to 1843 signals per call).  Every call on one GPU shares that GPU's array: calls that overlap on one GPU
+ * up to 1844 signals per call).  Every call on one GPU shares that GPU's array: calls that overlap on one GPU
  * (two streams, two host threads) race -- serialise them or use csc_mmpdf_batch with separate workspaces.
  * csc_static_scratch_bytes() returns the array's size. */
 size_t csc_static_scratch_bytes(void);
@@ -196,6 +196,44 @@ int csc_project_batch(const double* d_bank64, int K, int L, const double* d_sign
 int csc_match_batch(const double* d_bank64, int K, int L, const int32_t* d_true, int kt,
                     const int32_t* d_approx, int ka, int M, double pos_err_threshold,
                     double corr_err_threshold, int32_t* d_tp, void* stream);
+
+/* On-device constrained signal generator (benchmark input).  Replaces the per-signal loop of
+ * generateConstrainedSignalsDB / generateConstrainedTestSignal (src/csc/dictionary.py:271-324, 326-365): signal s
+ * = d_sparsity[s] unit-amplitude atoms at uniformly drawn (atom, position), a draw rejected when it lies closer
+ * than pos_err_threshold samples to (:305 `<`), or has a normalised inner product above corr_err_threshold with
+ * (:306 `>`), an atom already placed; plus white Gaussian noise of variance var(clean[|clean| > 1e-3]) /
+ * 10^(snr/10) (:318-322).  Philox-4x32-10 keyed by `seed`, counter = (draw / sample, first_index + s, stream): a
+ * signal depends on (seed, first_index + s) only.  The reference draws from NumPy's global RNG, so the STREAM is not
+ * reproduced -- parity is statistical (the constraints, the SNR rule), and the tests check exactly those.
+ *   d_sparsity [S] int32 (<= kmax), d_snr_db [S] f64, d_signals [S][N] f64 out, d_truth [S][kmax][2] int32 out
+ *   (pos, atom) in placement order, -1 padded; d_fail [S] int32 or NULL: 1 where 65536 draws did not place all atoms */
+int csc_generate_signals(const float* d_bank32t, const double* d_bank64, int K, int L, int N, int S,
+                         const int32_t* d_sparsity, const double* d_snr_db, int kmax, double pos_err_threshold,
+                         double corr_err_threshold, uint64_t seed, uint64_t first_index, double* d_signals,
+                         int32_t* d_truth, int32_t* d_fail, void* stream);
+
+/* Streaming writer of the sparVar result list (HOST function: every pointer is host memory).  Replaces the
+ * json.dump(results, f, indent=4, default=handle_non_serializable) that ends mmpdfSparVarPipelineFromDB
+ * (src/csc/dictionary.py:1148-1150, src/csc/utils.py:7-15) for the list under 'mmp': the SAME BYTES, written
+ * straight from the packed per-signal records of CSC_FLAG_RECORDS_AOS (K f64 mse | K x 2 i32 leaf | K x K x 2 i32
+ * (pos, atom)): per signal {"id", "snr", "results": [{"mse", "path", "atoms": [{"x","b","y","s"}], "delay"} for
+ * sparsity 1..K]} (src/csc/dictionary.py:1066-1071, src/csc/mmp.py:594-604).  Floats are formatted like Python's
+ * float.__repr__, 'path' is the base-`connections` digit string of the '<=' leaf (src/csc/mmp.py:303-313,586).
+ *   path, append      file to write ("wb") or to append to ("ab": the caller has written the dict's other members
+ *                     and the list's key, ending with `"mmp": `)
+ *   ids [S] int64; snr [S] f64, printed as an integer where snr_is_int[s] (NULL: always as a float)
+ *   delay             the 'delay' value of every result (the amortised per-signal time of the batched call)
+ *   atom_b/y/s [n_atoms] f64: the dictionary's parameters ('s' = the normalised sigma, src/csc/mmp.py:262)
+ *   indent_level      nesting depth of the list's key (1 for the pipelines' top-level dict)
+ *   close_object      also write the closing braces of the `indent_level` enclosing dicts
+ * Returns 0, or a negative code with csc_json_last_error().  csc_format_double writes repr(x) (NUL-terminated)
+ * and returns its length, or -1 if `cap` is too small. */
+int csc_sparvar_json_write(const char* path, int append, const void* records, int64_t S, int max_sparsity,
+                           int connections, const int64_t* ids, const double* snr, const uint8_t* snr_is_int,
+                           double delay, const double* atom_b, const double* atom_y, const double* atom_s,
+                           int n_atoms, int indent_level, int close_object);
+int csc_format_double(double x, char* out, int cap);
+const char* csc_json_last_error(void);
 
 /* Optional per-launch HIP-event timer.  No counterpart in the reference (its time_decorator,
  * src/csc/dictionary.py:25-45, logs host wall-clock per method); bench.py uses it to measure the

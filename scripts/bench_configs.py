@@ -47,18 +47,22 @@ def constrained(dic, n, N, sparsity, snr, seed):
     return np.array([dic.generateConstrainedTestSignal(N, sparsity, snr, 10, 0.75)[0] for _ in range(n)])
 
 
+ONLY_LARGE = "--only-large" in sys.argv
 small = bench.canonical_dictionary()
-run("1: OMP 200 signals sparsity 3 SNR 10", small, constrained(small, 200, 738, 3, 10, 0), 3, 1, 1, 1.0)
-sig2 = bench.make_signals(small, 0)
-run("2: sparVar 3200 signals c3 B3 K5", small, sig2, 5, 3, 3, 0.8)
-run("4a: deep tree c4 B4 K7, 3200 signals", small, sig2, 7, 4, 4, 0.8)
-run("4b: deep tree c4 B64 K7 (341 nodes), 800 signals", small, sig2[::4], 7, 4, 64, 0.8)
-run("2b: sparVar c3 B10 K10 (reference defaults), 3200 signals", small, sig2, 10, 3, 10, 0.8)
-# config 5, one GPU's share: 125 000 signals (1M over 8 GPUs) in ONE call, config-2 recipe tiled with noise
-rng = np.random.default_rng(7)
-sig5 = np.tile(sig2, (40, 1))[:125000] + 0.01 * rng.standard_normal((125000, 738))
-run("5 (one GPU's share): 125000 signals c3 B3 K5", small, sig5, 5, 3, 3, 0.8, reps=2)
-del sig5
+if ONLY_LARGE:
+    sys.argv.append("--skip-small")
+if "--skip-small" not in sys.argv:
+  run("1: OMP 200 signals sparsity 3 SNR 10", small, constrained(small, 200, 738, 3, 10, 0), 3, 1, 1, 1.0)
+  sig2 = bench.make_signals(small, 0)
+  run("2: sparVar 3200 signals c3 B3 K5", small, sig2, 5, 3, 3, 0.8)
+  run("4a: deep tree c4 B4 K7, 3200 signals", small, sig2, 7, 4, 4, 0.8)
+  run("4b: deep tree c4 B64 K7 (341 nodes), 800 signals", small, sig2[::4], 7, 4, 64, 0.8)
+  run("2b: sparVar c3 B10 K10 (reference defaults), 3200 signals", small, sig2, 10, 3, 10, 0.8)
+  # config 5, one GPU's share: 125 000 signals (1M over 8 GPUs) in ONE call, config-2 recipe tiled with noise
+  rng = np.random.default_rng(7)
+  sig5 = np.tile(sig2, (40, 1))[:125000] + 0.01 * rng.standard_normal((125000, 738))
+  run("5 (one GPU's share): 125000 signals c3 B3 K5", small, sig5, 5, 3, 3, 0.8, reps=2)
+  del sig5
 if "--no-large" not in sys.argv:
     t0 = time.time()
     large = csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.0005), np.arange(0.010, 0.036, 0.0003), [1])
@@ -70,3 +74,5 @@ if "--no-large" not in sys.argv:
     torch.cuda.synchronize()
     print(json.dumps({"large_similarity_table_s": time.time() - t0}), flush=True)
     run("3: 9570-atom dictionary c3 B3 K5, %d signals" % n, large, sig3, 5, 3, 3, 0.8, reps=2)
+    large.device_bank().fp32_only = True
+    run("3 (CSC_FLAG_FP32_ONLY): 9570-atom dictionary c3 B3 K5, %d signals" % n, large, sig3, 5, 3, 3, 0.8, reps=1)

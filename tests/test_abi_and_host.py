@@ -52,8 +52,9 @@ def test_sizes_helpers():
     lib = _lib.lib()
     # per 144-atom tile: 16 slabs x 9 column blocks x (32 x 16) floats + 208 ints of metadata + the same blocks in fp16;
     # then max_k ||a_k||^2 (+ spare) and ||a_k||^2 as doubles
-    assert lib.csc_bank32_elems(143, 492) == 512 * 144 + 208 + 256 * 144 + 16 + 2 * 143
-    assert lib.csc_bank32_elems(145, 492) == 2 * (512 * 144 + 208 + 256 * 144) + 16 + 2 * 145
+    # ... and the bank as a scaled two-term fp16 number (hi + lo) for the tiled kernel's three-product filter
+    assert lib.csc_bank32_elems(143, 492) == 512 * 144 + 208 + 256 * 144 + 16 + 2 * 144 + 512 * 144
+    assert lib.csc_bank32_elems(145, 492) == 2 * (512 * 144 + 208 + 256 * 144) + 16 + 2 * 146 + 2 * 512 * 144
     assert lib.csc_sim_words(738, 492) == 2 * ((2 * 247 - 1 + 63) // 64)
     assert lib.csc_sim_words(100, 492) == 0
     # per frontier node: N residual samples + the packed Cholesky factor (15 doubles at depth 5)
@@ -167,3 +168,20 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+
+
+def test_torch_custom_ops_registered_with_shape_inference():
+    """csc_amd.ops registers torch.ops.csc_amd.{bank_pack, similarity_table, mmpdf_batch}; their fake implementations
+    infer the output shapes without a GPU (what torch.compile / export need)."""
+    import torch
+    import csc_amd.ops  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        b64 = torch.empty((143, 492), dtype=torch.float64, device="cuda")
+        b32 = torch.ops.csc_amd.bank_pack(b64)
+        sim = torch.ops.csc_amd.similarity_table(b64, 738, 0.8)
+        sig = torch.empty((10, 738), dtype=torch.float64, device="cuda")
+        pos, atom, mse, rec = torch.ops.csc_amd.mmpdf_batch(b32, b64, sim, sig, 5, 3, 3, 0)
+    from csc_amd import _lib
+    assert b32.shape == (_lib.lib().csc_bank32_elems(143, 492),) and sim.shape == (143 * 143 * 16,)
+    assert pos.shape == atom.shape == mse.shape == (10, 15) and rec.shape == (10, 280) and rec.dtype == torch.uint8

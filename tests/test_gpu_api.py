@@ -522,3 +522,82 @@ def test_random_shapes_matching_pursuit_vs_oracle():
                 want = float(np.mean((sigs[s] - approx) ** 2))
                 assert abs(mse[s, i] - want) <= 1e-9 * want, (trial, s, i)
                 prev = m
+
+
+def test_device_generator_constraints_and_snr(dic):
+    """csc_generate_signals (the on-device twin of generateConstrainedSignalsDB, reference dictionary.py:271-365).
+    Its random stream is Philox, not NumPy's global generator, so the stream is not comparable ("parity unpinned" for
+    the draws); what the reference's generator guarantees is checked instead, on every signal: the number of atoms,
+    positions inside [0, P), |delta pos| >= pos_err_threshold and normalised inner product <= corr_err_threshold for
+    every pair, signal = unit-amplitude atoms + noise whose power follows the reference's SNR rule
+    (var(clean[|clean| > 1e-3]) / 10^(snr/10)), uniform draws, determinism in (seed, signal id)."""
+    bank64 = dic.getLocalDictionary()
+    K, L = bank64.shape
+    N, P = 738, 247
+    g = dic.generateConstrainedSignalsDevice(150, N, [2, 3, 4, 5], [0, 5, 10, 15], 10, 0.75, seed=5)
+    sig, truth = g["signals"].cpu().numpy(), g["truth"]
+    S = len(sig)
+    assert S == 2400 and list(g["ids"][:3]) == [0, 1, 2] and list(g["snr"][[0, 599, 600]]) == [0, 0, 5]
+    assert list(g["sparsity"][[0, 149, 150, 599]]) == [2, 2, 3, 5]
+    norms = np.linalg.norm(bank64, axis=1)
+    ratio = []
+    for s in range(S):
+        pl = [(int(p), int(k)) for p, k in truth[s] if p >= 0]
+        assert len(pl) == g["sparsity"][s] and all(0 <= p < P and 0 <= k < K for p, k in pl)
+        clean = np.zeros(N)
+        for p, k in pl:
+            clean[p:p + L] += bank64[k]
+        for i in range(len(pl)):
+            for j in range(i):
+                (p1, k1), (p2, k2) = pl[i], pl[j]
+                assert abs(p1 - p2) >= 10
+                a1, a2 = np.zeros(N), np.zeros(N)
+                a1[p1:p1 + L], a2[p2:p2 + L] = bank64[k1], bank64[k2]
+                assert a1 @ a2 / (norms[k1] * norms[k2]) <= 0.75 + 1e-12
+        noise = sig[s] - clean
+        want = np.var(clean[np.abs(clean) > 1e-3]) / 10 ** (g["snr"][s] / 10)
+        ratio.append(np.mean(noise ** 2) / want)
+    ratio = np.array(ratio)
+    # 738 Gaussian samples per signal: the per-signal power ratio scatters by sqrt(2/738) = 5 %; its mean by 0.1 %
+    assert abs(ratio.mean() - 1) < 0.01 and 0.75 < ratio.min() and ratio.max() < 1.3
+    # noise is white and centred; atoms and positions are drawn over the whole range
+    allnoise = np.concatenate([sig[s] - sum(np.pad(bank64[k], (p, N - L - p)) for p, k in truth[s] if p >= 0)
+                               for s in range(0, S, 40)])
+    z = allnoise.reshape(-1, N) / allnoise.reshape(-1, N).std(axis=1, keepdims=True)
+    assert abs(z.mean()) < 0.02 and abs(np.mean(z[:, 1:] * z[:, :-1])) < 0.02 and abs(np.mean(z ** 4) - 3) < 0.15
+    atoms = truth[..., 1][truth[..., 1] >= 0]
+    pos = truth[..., 0][truth[..., 0] >= 0]
+    assert len(np.unique(atoms)) == K and pos.min() < 5 and pos.max() > P - 6
+    # determinism: same (seed, first_index) -> same bits; a signal depends on its id only; another seed differs
+    g2 = dic.generateConstrainedSignalsDevice(150, N, [2, 3, 4, 5], [0, 5, 10, 15], 10, 0.75, seed=5)
+    assert np.array_equal(g2["signals"].cpu().numpy(), sig) and np.array_equal(g2["truth"], truth)
+    g3 = dic.generateConstrainedSignalsDevice(150, N, [2], [0], 10, 0.75, seed=5, first_index=0)
+    assert np.array_equal(g3["signals"].cpu().numpy(), sig[:150])
+    g4 = dic.generateConstrainedSignalsDevice(150, N, [2], [0], 10, 0.75, seed=6)
+    assert not np.array_equal(g4["truth"], truth[:150, :2])
+    # and the solver takes the tensor as it is
+    res = dic.mmpdfSparVarBatch(g["signals"][:64], 3, 0.8, 3, 5)
+    assert len(res) == 64 and np.isfinite(res.mse).all()
+
+
+def test_torch_custom_ops_match_the_engine(golden_signals):
+    """torch.ops.csc_amd.* (csc_amd/ops.py: torch.library registrations over the C ABI, the route BASELINE.json's north
+    star names) give the engine's results bit for bit."""
+    import torch
+    import csc_amd
+    import csc_amd.ops  # noqa: F401  (registers the ops)
+    d = csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.005), np.arange(0.010, 0.036, 0.002), [1])
+    bank = d.device_bank()
+    b64 = bank.bank64
+    b32 = torch.ops.csc_amd.bank_pack(b64)
+    assert torch.equal(b32.view(torch.int32), bank.bank32t.view(torch.int32))      # bit for bit (the image holds ints too)
+    sim = torch.ops.csc_amd.similarity_table(b64, 738, 0.8)
+    assert torch.equal(sim, bank.similarity_table(738, 0.8))
+    sig = torch.from_numpy(golden_signals["signals"][:24]).to(bank.device)
+    pos, atom, mse, rec = torch.ops.csc_amd.mmpdf_batch(b32, b64, sim, sig, 5, 3, 3, 0)
+    ref = bank.mmpdf_launch(sig, 5, 3, 3, 0.8, want_coef=False)
+    assert torch.equal(pos, ref["node_pos"]) and torch.equal(atom, ref["node_atom"]) and torch.equal(mse, ref["node_mse"])
+    assert torch.equal(rec, ref["rec_buf"])
+    # OMP through the op: no similarity table
+    pos1, _, _, _ = torch.ops.csc_amd.mmpdf_batch(b32, b64, None, sig, 3, 1, 1, 0)
+    assert torch.equal(pos1[:, 0], pos[:, 0])

@@ -178,3 +178,40 @@ def test_candidate_overflow_same_choice_in_register_and_tiled_kernels():
         assert r.stats[0] == 6, (name, r.stats)                         # every selection overflowed
         got[name] = (r.node_pos[:, 0].astype(np.int64) * 143 + r.node_atom[:, 0]).tolist()
     assert got["register"] == got["register fp32"] == got["tiled"] == want, got
+
+
+def test_three_product_filter_equals_fp32_path(large_dic):
+    """Dictionaries beyond one register tile take a node's correlations on the fp16 matrix cores as a three-product
+    filter (two-term fp16 operands, mmp_level_tiled16_kernel) and re-score its band in float64; with
+    CSC_FLAG_FP32_ONLY the fp32 kernel does everything.  Same selections, bit-identical MSE and coefficients (the
+    least squares behind the choice is the same code), on BASELINE config 3's dictionary and on a small multi-unit
+    one (remainder row tile, partly filled column tile, 3 connections); and the filter settles (nearly) every node
+    itself: stats[3] counts the nodes handed to the fp32 kernel."""
+    import csc_amd
+    z = np.load(os.path.join(GOLDEN, "large.npz"))
+    cases = [(large_dic, z["signals"], (5, 3, 3, 0.8))]
+    b, y = np.arange(0.005, 0.06, 0.0025), np.arange(0.010, 0.036, 0.0018)
+    d2 = csc_amd.ZSDictionary.from_values(b, y, [1])
+    rng = np.random.default_rng(17)
+    L2 = d2.getAtomsLength()
+    bank2 = d2.getLocalDictionary()
+    for P in (260, 272, 200):                                     # remainder tile of 4 and of 16 rows; a single row block
+        sig = 0.02 * rng.standard_normal((12, L2 + P - 1))
+        for srow in sig:
+            for _ in range(3):
+                srow[rng.integers(0, P):][:L2] += rng.uniform(0.5, 1.5) * bank2[rng.integers(len(bank2))]
+        cases.append((d2, sig, (4, 3, 10, 0.7)))
+    for dic, sigs, (Kx, c, B, thr) in cases:
+        bank = dic.device_bank()
+        try:
+            bank.fp32_only = False
+            got = bank.mmpdf_batch(sigs, Kx, c, B, thr, want_coef=True)
+            bank.fp32_only = True
+            ref = bank.mmpdf_batch(sigs, Kx, c, B, thr, want_coef=True)
+        finally:
+            bank.fp32_only = False
+        assert ref.stats[3] == 0 and got.stats[0] == 0
+        n_nodes = len(sigs) * (1 + sum(got.level_sizes[:-1]))
+        assert got.stats[3] <= 0.05 * n_nodes, (got.stats, n_nodes)
+        for name in ("node_pos", "node_atom", "node_mse", "node_coef", "rec_mse", "rec_leaf", "rec_sel"):
+            assert np.array_equal(getattr(got, name), getattr(ref, name)), (name, len(bank.bank64))

@@ -243,6 +243,54 @@ def test_sparvar_pipeline_json(dic, golden_signals, tmp_path):
         dic.mmpdfSparVarPipelineFromDB(src, dst, 1)
 
 
+def test_streaming_writer_is_byte_identical_to_json_dump(dic, golden_signals, tmp_path):
+    """csc_sparvar_json_write (the pipelines' writer) emits exactly the bytes of the reference's
+    json.dump(results, indent=4, default=handle_non_serializable) (reference dictionary.py:1148-1150, utils.py:7-15):
+    int and float snr values, ids out of order, awkward floats in the records, 0 / 1 / many signals, the
+    SparVarBatch front-ends."""
+    import csc_amd
+    from csc_amd.utils import handle_non_serializable
+    sigs = golden_signals["signals"][[3, 17, 40, 41, 63]]
+    res, dt = dic._batch(sigs, 5, 3, 3, 0.8, fields="rec")
+    res.rec_mse[1, 0], res.rec_mse[2, 3], res.rec_mse[3, 1] = 1e-5, 123456789012345680.0, 1.0   # exponent / integral forms
+    ids, snrs = [7, 3, 10 ** 12, 0, -4], [10, 2.5, 0, 15.0, 1e-7]
+    header = {"source": "db.json", "date": "241008", "algorithm": "Convolutional MMP-DF", "nbBranches": 3,
+              "connections": 3, "dissimilarity": 0.8, "maxSparsityLevel": 5, "batchSize": 1, "snrLevels": [0, 5.5],
+              "signalLength": 738, "sparsityLevels": [2, 3], "dictionary": str(dic)}
+    for n in (5, 1, 0):
+        sub, _ = dic._batch(sigs[:max(n, 1)], 5, 3, 3, 0.8, fields="rec")
+        sub.rec_mse[:] = res.rec_mse[:max(n, 1)]
+        if n == 0:
+            sub = csc_amd.engine.BatchResult.from_records(sub.to_records("rec")[:0], 5, 3, 3, False, fields="rec")
+        want = dict(header, mmp=[{"id": ids[i], "snr": snrs[i], "results": dic._sparvar_records(sub, i, 0.125)}
+                                 for i in range(n)])
+        a, b = str(tmp_path / f"a{n}.json"), str(tmp_path / f"b{n}.json")
+        with open(a, "w") as f:
+            json.dump(want, f, indent=4, default=handle_non_serializable)
+        assert dic._dump_sparvar_stream(header, "mmp", sub, ids[:n], snrs[:n], 0.125, b)
+        assert open(a, "rb").read() == open(b, "rb").read(), n
+    # ids / snr values the fast writer does not take are left to json.dump
+    assert not dic._dump_sparvar_stream(header, "mmp", res, ["a"] * 5, snrs, 0.1, str(tmp_path / "c.json"))
+    # float formatting alone, against Python's repr
+    import ctypes as C
+    from csc_amd import _lib
+    buf = C.create_string_buffer(64)
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([rng.standard_normal(2000) * 10.0 ** rng.integers(-12, 20, 2000),
+                           rng.integers(0, 2 ** 63, 2000).astype(np.uint64).view(np.float64),
+                           [0.0, -0.0, 1e16, 1e-4, 9.999e-5, 5e-324, 1.7976931348623157e308, np.inf, -np.inf, np.nan]])
+    for v in vals:
+        assert _lib.lib().csc_format_double(float(v), buf, 64) > 0 and buf.value.decode() == json.dumps(float(v)), v
+    # array front-ends: JSON and the uncompressed binary records round-trip
+    batch = dic.mmpdfSparVarBatch(sigs, 3, 0.8, 3, 5)
+    batch.save_json(str(tmp_path / "s.json"), ids=ids, snrs=snrs, header=header)
+    out = json.load(open(tmp_path / "s.json"))
+    assert [m["id"] for m in out["mmp"]] == ids and strip_delay(out["mmp"][4]) == strip_delay(batch.record(4, ids[4], snrs[4]))
+    batch.save_records(str(tmp_path / "r.npy"))
+    back = csc_amd.dictionary.SparVarBatch.load_records(dic, str(tmp_path / "r.npy"))
+    assert np.array_equal(back.mse, batch.mse) and np.array_equal(back.pos, batch.pos) and back.path(2, 5) == batch.path(2, 5)
+
+
 def test_other_pipelines_json(dic, golden_signals, tmp_path):
     idx = [5, 21, 37]
     src = str(tmp_path / "db.json")
