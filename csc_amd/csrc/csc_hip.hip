@@ -102,6 +102,8 @@ struct LevelArgs {
     int S;                // signals
     const double* signals;    // [S][N]            } the chain kernels walk several levels: level e reads
     double* ws[2];            // [S][F][NS] each   } signals (e == 0) or ws[e & 1] and writes ws[(e + 1) & 1]
+    int picks_only;       // level 0 ahead of the chain kernel: write the children's (pos, atom) and <atom, signal> only
+    int from_root;        // chain kernel: build the level-1 node from the signal and the root level's pick
     TreeShape ts;
 };
 
@@ -1175,7 +1177,10 @@ __device__ __forceinline__ void suppress_similar(const LevelArgs& a, NodeLds* sl
     __syncthreads();
     PROF_MARK(11);
     // this lane's 16 entries of a column tile are bits dp0 + 16*mi + rg of the column's row, dp0 >= 0: a window of
-    // 52 bits, i.e. three words per column tile (one LDS read per entry cost a full LDS latency each, 144 times)
+    // 52 bits, i.e. three words per column tile (one LDS read per entry cost a full LDS latency each, 144 times).
+    // The similarity disk of an atom covers a few hundred of the 35 k entries: a column tile in which no lane's window
+    // holds a set bit is skipped as a whole (wave-uniform), and where there are hits an entry's test is one shift of
+    // the lane's window by a constant.
     const int dp0 = 64 * wave + 4 * (lane >> 4) - p_sel + P - 1;
     const int w0 = dp0 >> 5, b0 = dp0 & 31;
     bool any = false;
@@ -1183,13 +1188,14 @@ __device__ __forceinline__ void suppress_similar(const LevelArgs& a, NodeLds* sl
     for (int ni = 0; ni < NT; ++ni) {
         const uint32_t* row = simrow + max(permv[ni], 0) * W1;
         const uint32_t wd0 = row[min(w0, W - 1)], wd1 = row[min(w0 + 1, W - 1)], wd2 = row[min(w0 + 2, W - 1)];
+        const uint64_t lo64 = (uint64_t)wd0 | ((uint64_t)wd1 << 32);
+        const uint64_t win = ((lo64 >> b0) | (b0 ? (uint64_t)wd2 << (64 - b0) : 0ull)) & ((1ull << 52) - 1);   // bits 16 mi + rg
+        if (__ballot(win != 0ull) == 0ull) continue;                 // nothing of this column tile is suppressed
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int off = b0 + 16 * mi + rg;                   // < 32 + 52
-                const uint32_t wd = off < 32 ? wd0 : (off < 64 ? wd1 : wd2);
-                const bool hit = ((wd >> (off & 31)) & 1u) && acc[mi][ni][rg] > -INFINITY;
+                const bool hit = ((win >> (16 * mi + rg)) & 1ull) && acc[mi][ni][rg] > -INFINITY;
                 acc[mi][ni][rg] = hit ? __uint_as_float(SUPP_BITS) : acc[mi][ni][rg];
                 any |= hit;
             }
@@ -1309,7 +1315,25 @@ __device__ __forceinline__ bool select_children(const LevelArgs& a, NodeLds* sl,
         PROF_MARK(5);
         const int jc = j + t * stride;                               // child's index in level d+1
         const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
-        child_solve_and_write(a, sl, r64, s, jc, cid, d, rout_base, false);
+        if (a.picks_only) {
+            // the chain kernel, launched behind, builds this child itself (residual, factor, MSE) from the signal: only
+            // the pick goes to HBM -- (pos, atom) and <atom, signal>, the latter parked in the child's MSE slot.  That
+            // inner product is the re-scored value; a choice that was not a re-scored candidate computes it the way
+            // child_solve_and_write does (one wave, same sum)
+            if (!sl->beta_ok && wave == 0) {
+                double v = dot_range<64>(a.bank64 + (size_t)sl->sup_atom[d] * a.L, r64 + sl->sup_pos[d], 0, a.L, lane);
+                v = wave_sum(v);
+                if (lane == 63) sl->beta = v;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                a.node_pos[cid] = sl->sup_pos[d];
+                a.node_atom[cid] = sl->sup_atom[d];
+                a.node_mse[cid] = sl->beta;
+            }
+        } else {
+            child_solve_and_write(a, sl, r64, s, jc, cid, d, rout_base, false);
+        }
         __syncthreads();
     }
     return true;
@@ -1625,9 +1649,27 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
     if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
 
     PROF_INIT(16);
-    const double* rin = d0 == 0 ? a.signals + s * (size_t)N : a.ws[d0 & 1] + (s * Fd + j) * (size_t)a.NS;
+    const double* rin = (d0 == 0 || a.from_root) ? a.signals + s * (size_t)N : a.ws[d0 & 1] + (s * Fd + j) * (size_t)a.NS;
     double rnorm2, first[4];
-    node_prologue(a, sl, r64, nullptr, Npad, 0, rin, s, j, rnorm2, first, d0);
+    bool reload_first = false;
+    node_prologue(a, sl, r64, nullptr, Npad, 0, rin, s, j, rnorm2, first, a.from_root ? 0 : d0);
+    if (a.from_root) {
+        // d0 = 1 and the root level left only its pick: this node is the signal's child (pos, atom) with <atom, signal>
+        // parked in its MSE slot.  Its least squares, residual, factor and MSE are child_solve_and_write's at depth 0,
+        // bit for bit what the register-resident kernel writes; they stay in LDS.
+        const size_t cid = s * a.NN + a.ts.off[1] + j;
+        if (tid == 0) {
+            sl->sup_pos[0] = a.node_pos[cid];
+            sl->sup_atom[0] = a.node_atom[cid];
+            sl->beta = a.node_mse[cid];
+            sl->beta_ok = 1;
+        }
+        __syncthreads();
+        child_solve_and_write(a, sl, r64, s, j, cid, 0, nullptr, true);
+        __syncthreads();
+        rnorm2 = sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3];
+        reload_first = true;
+    }
     PROF_MARK(0);
     const float am2 = *a.amax2, am = sqrtf(am2);
     const float band = 2.f * ((9.765625e-04f + DELTA_REL + 1e-6f) * am + 2.9802322e-08f * sqrtf((float)L) * (1.f + am));
@@ -1648,7 +1690,7 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
     auto give_up = [&](int d) {
         int tq = threadIdx.x;
         asm volatile("" : "+v"(tq));                                  // keeps the address parts out of the loop above
-        if (d > d0) {
+        if (d > d0 || a.from_root) {                                  // (from the root: nobody wrote level d0's row)
             double* row = a.ws[d & 1] + (s * Fd + j) * (size_t)a.NS;
             for (int n = tq; n < N; n += WG) row[n] = r64[n];
             if (tq < TRI(d)) row[N + tq] = sl->Lf[tq];
@@ -1663,7 +1705,7 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
     // ---- the chain: this node, its child, its grandchild ... down to the leaves; the residual, the Cholesky
     // factor and the coefficients stay in LDS from one level to the next, only the node tables go to HBM
     for (int d = d0; d < a.Kmax; ++d) {
-        if (d > d0) {                                                 // the window elements build_r16 wants in registers
+        if (d > d0 || reload_first) {                                 // the window elements build_r16 wants in registers
             int tq = threadIdx.x;
             asm volatile("" : "+v"(tq));
 #pragma unroll
@@ -3021,6 +3063,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
 
     double* ws[2] = {static_cast<double*>(d_workspace), static_cast<double*>(d_workspace) + node_bytes / 16};
     hipStream_t st = (hipStream_t)stream;
+    bool picked = false;                                              // level 0 wrote picks only
     for (int d = 0; d < max_sparsity; ++d) {
         LevelArgs a;
         a.bank32t = d_bank32t; a.meta = bank_meta(d_bank32t, K, L); a.bank64 = d_bank64; a.sim_bits = d_sim_bits;
@@ -3040,6 +3083,10 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         if (grid > 0x7fffffffULL) FAIL(-11, "batch too large for one launch (%zu workgroups)", grid);
         const int span = timer_begin(st, d);
         a.flags = nullptr; a.S = S; a.signals = d_signals; a.ws[0] = ws[0]; a.ws[1] = ws[1];
+        a.picks_only = 0; a.from_root = 0;
+        // level 0 in front of the chain kernel (every node of level 1 has one child): it only has to pick -- the chain
+        // kernel builds a pick's node from the signal, so no child residual crosses HBM between the two launches
+        const bool root_picks = lean && mode == 0 && d == 0 && max_sparsity > 1 && connections > 1 && ts.pw[1] >= ts.F[2];
         bool chain = false;
         if (tiled16) {
             // the three-product fp16 filter takes the level; the fp32 kernel behind it redoes the flagged nodes
@@ -3050,6 +3097,11 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
             hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
         } else if (tiled) {
             hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
+        } else if (root_picks) {
+            a.picks_only = 1;
+            a.resid_out = nullptr;
+            hipLaunchKernelGGL(mmp_level_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
+            picked = true;
         } else if (lean && (connections == 1 || ts.pw[d] >= ts.F[d + 1])) {
             // every node of this level has one child (node j's second child j + pw[d] falls outside F[d + 1]), and
             // so has every node below (pw grows, F stays at `branches`): ONE launch walks each of these chains down
@@ -3057,6 +3109,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
             // of config 2 take 187 instead of 231 us).  With siblings the lean kernel would repeat its sweeps per
             // sibling and the register-resident kernel wins
             a.flags = node_flags;
+            a.from_root = picked ? 1 : 0;
             chain = true;
             hipLaunchKernelGGL(mmp_level_lean_kernel, dim3((unsigned)grid), dim3(WG), lean_lds_bytes(N), st, a);
             hipLaunchKernelGGL(mmp_level_followup_kernel, dim3((unsigned)((grid + FOLLOW_NODES - 1) / FOLLOW_NODES)),
