@@ -670,6 +670,28 @@ __global__ __launch_bounds__(WG, 2) void correlate_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// float64 correlations for the public API (computeCorrelations / the rmatvec of getMaskedConvOperator)
+// ------------------------------------------------------------------------------------------------
+// The matrix-core kernel above returns fp32-accurate values; a caller that runs its own solver on the operator (lsqr's
+// orthogonality) needs the reference's float64 (src/csc/dictionary.py:395-407 is float64 FFT arithmetic, ~1e-12).
+// One workgroup per (signal, position): the window sits in LDS, one wave per atom at a time, fp64 FMA + wave sum.
+__global__ __launch_bounds__(WG) void correlate64_kernel(const double* __restrict__ bank64, int K, int L,
+                                                         const double* __restrict__ signals, int N, int P,
+                                                         double* __restrict__ out) {
+    extern __shared__ double win[];                                   // [L]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t b = blockIdx.y;
+    const int p = blockIdx.x;
+    for (int i = tid; i < L; i += WG) win[i] = signals[b * N + p + i];
+    __syncthreads();
+    for (int k = wave; k < K; k += WG / 64) {
+        double v = dot_range<64>(bank64 + (size_t)k * L, win, 0, L, lane);
+        v = wave_sum(v);
+        if (lane == 63) out[(b * P + p) * K + k] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // batched projection on given supports (API parity: getSignalProjectionFromAtoms)
 // ------------------------------------------------------------------------------------------------
 struct ProjLds {
@@ -2004,7 +2026,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled_kernel(const LevelArgs 
     double* r64 = lds_raw + SLABF;                                    // [Npad]
     float* r32 = reinterpret_cast<float*>(r64 + Npad);                // [R32]
     NodeLds* sl = reinterpret_cast<NodeLds*>(r32 + ((R32 + 3) & ~3));
-    PROF_INIT(0);
+    PROF_INIT(16);
     TiledLds* tl2 = reinterpret_cast<TiledLds*>(sl + 1);
 
     const int Fd = a.ts.F[d], Fc = a.ts.F[d + 1];
@@ -2312,6 +2334,105 @@ __device__ __forceinline__ void gemm16x3_group(const _Float16* __restrict__ hi, 
     __syncthreads();
 }
 
+// The screen of a unit: the hi x hi product alone (one MFMA per tile and slab instead of three), good to
+//     eps1 = (2^-10 + 2^-14 + 1e-6) am + 2^-25 sqrt(L) (1 + am)
+// like the single-term filter of the untiled kernels (two operand roundings of 2^-11 each, fp32 accumulation of L <= 682
+// products, fp16 subnormals).  Only the hi blocks of a group-slab are staged (3 KiB, contiguous in the image: 768 B per
+// wave, one copy each), and the Hankel structure halves the A reads: the fragment of row tile mi + 2 at slab s IS the
+// fragment of row tile mi at slab s + 1 (rows 32 further = one slab further along the window), so the six fragments
+// w[0..5] rotate with period 3 and each slab requests only two new ones.
+__device__ __forceinline__ void stage_group16x1(const _Float16* hi_slab, _Float16* lslot, int g, int wave, int lane) {
+    if (lane < 48)
+        __builtin_amdgcn_global_load_lds((gptr_t)(hi_slab + NG * g * BLKF + wave * 384 + lane * 8),
+                                         (lptr_t)(lslot + wave * 384), 16, 0, 0);
+}
+
+template <bool REM>
+__device__ __forceinline__ void gemm16x1_group(const _Float16* __restrict__ hi, int g, int s0, int s1, const _Float16* rh,
+                                               int R16T_CS, int rowbase, _Float16* ring, f32x4 (&acc)[MT][NG], f32x4& accr) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NG; ++nj) acc[mi][nj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    accr = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const _Float16* pa = rh + (lr & 7) * R16T_CS + rowbase + 64 * wave + (lr & 8) + 8 * lq;    // W(i) = pa[16 i ..]
+    const _Float16* pr = rh + (lr & 7) * R16T_CS + rowbase + CSC_TILE_ROWS + (lr & 8) + 8 * lq;
+    WAIT_VM(0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (s0 + q < s1) stage_group16x1(hi + (size_t)(s0 + q) * SLABF, ring + q * TG_BLK, g, wave, lane);
+    f16x8 w[6], ar[3], b[3][NG];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned m0 = wave == 0 ? ~0u : 0u, m1 = wave == 1 ? ~0u : 0u, m2 = wave >= 2 ? ~0u : 0u;
+#define T1_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, C, 0, 0, 0)
+    // slab s with the fragments of phase ph: w[2 ph .. 2 ph + 3 (mod 6)], ar[ph], b[ph]; requests those of slab s + 1
+    // (the window has one slab of look-ahead, so the last slab's requests stay inside it and are simply not used)
+    auto body = [&](auto phc, int s, int slot) {
+        constexpr int ph = decltype(phc)::value, pn = (ph + 1) % 3;
+        constexpr int i0 = (2 * ph) % 6, i1 = (2 * ph + 1) % 6, i2 = (2 * ph + 2) % 6, i3 = (2 * ph + 3) % 6;
+        constexpr int l0 = (2 * ph + 4) % 6, l1 = (2 * ph + 5) % 6;
+        __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));   // lgkmcnt(0)
+        w[l0] = *reinterpret_cast<const f16x8*>(pa + 32 * s + 64);
+        w[l1] = *reinterpret_cast<const f16x8*>(pa + 32 * s + 80);
+        if (REM) ar[pn] = *reinterpret_cast<const f16x8*>(pr + 32 * s + 32);
+        f16x8 bw;
+        if (REM) {
+            const u32x4 r = (__builtin_bit_cast(u32x4, b[ph][0]) & m0) | (__builtin_bit_cast(u32x4, b[ph][1]) & m1) |
+                            (__builtin_bit_cast(u32x4, b[ph][2]) & m2);
+            bw = __builtin_bit_cast(f16x8, r);
+        }
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+            T1_MFMA(w[i0], b[ph][nj], acc[0][nj]);
+            T1_MFMA(w[i1], b[ph][nj], acc[1][nj]);
+            T1_MFMA(w[i2], b[ph][nj], acc[2][nj]);
+            T1_MFMA(w[i3], b[ph][nj], acc[3][nj]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < s1) WAIT_VM(1); else WAIT_VM(0);                 // my copy of slab s + 1 has landed
+        __builtin_amdgcn_s_barrier();                                // ... everybody's; slab s - 1's slot is free
+        if (s + 3 < s1) stage_group16x1(hi + (size_t)(s + 3) * SLABF, ring + ((slot + 3) & (TRING - 1)) * TG_BLK, g, wave, lane);
+        {
+            const _Float16* sb = ring + ((slot + (s + 1 < s1 ? 1 : 0)) & (TRING - 1)) * TG_BLK + lane * 8;
+#pragma unroll
+            for (int nj = 0; nj < NG; ++nj) b[pn][nj] = *reinterpret_cast<const f16x8*>(sb + nj * BLKF);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        T1_MFMA(w[i0], b[ph][2], acc[0][2]);
+        T1_MFMA(w[i1], b[ph][2], acc[1][2]);
+        T1_MFMA(w[i2], b[ph][2], acc[2][2]);
+        T1_MFMA(w[i3], b[ph][2], acc[3][2]);
+        if (REM) T1_MFMA(ar[ph], bw, accr);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (s0 < s1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = *reinterpret_cast<const f16x8*>(pa + 32 * s0 + 16 * i);
+        if (REM) ar[0] = *reinterpret_cast<const f16x8*>(pr + 32 * s0);
+        const int later = min(2, s1 - 1 - s0);
+        if (later == 2) WAIT_VM(2); else if (later == 1) WAIT_VM(1); else WAIT_VM(0);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int nj = 0; nj < NG; ++nj) b[0][nj] = *reinterpret_cast<const f16x8*>(ring + lane * 8 + nj * BLKF);
+    }
+    int s = s0, slot = 0;
+    while (s < s1) {
+        body(std::integral_constant<int, 0>{}, s, slot);
+        ++s; slot = (slot + 1) & (TRING - 1);
+        if (s >= s1) break;
+        body(std::integral_constant<int, 1>{}, s, slot);
+        ++s; slot = (slot + 1) & (TRING - 1);
+        if (s >= s1) break;
+        body(std::integral_constant<int, 2>{}, s, slot);
+        ++s; slot = (slot + 1) & (TRING - 1);
+    }
+#undef T1_MFMA
+    __syncthreads();
+}
+
 // masking of the entries outside the matrix + suppression by the first t siblings (bits from the similarity table);
 // returns the lane's maximum over its unsuppressed entries (remainder tile included), lane_supp = it holds a
 // suppressed one
@@ -2419,7 +2540,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
     _Float16* rl = rh + R16_COPIES * R16T_CS;
     _Float16* ring = rl + R16_COPIES * R16T_CS;
     NodeLds* sl = reinterpret_cast<NodeLds*>(ring + TRING * TG_BLK);
-    PROF_INIT(0);
+    PROF_INIT(16);                                                   // (the shared phases' marks: slots 16.., 0..15 are this kernel's own counters)
     Tiled16Lds* tl = reinterpret_cast<Tiled16Lds*>(sl + 1);
 
     const int Fd = a.ts.F[d], Fc = a.ts.F[d + 1];
@@ -2462,7 +2583,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
     f32x4 acc[MT][NG], accr;
     int permv[NG], permr;
     // one unit: GEMM + masks + suppression; the unscaled lane maximum
-    auto unit = [&](int u, int t, bool& lane_supp, int& rowbase) -> float {
+    auto unit = [&](int u, int t, bool screen, bool& lane_supp, int& rowbase) -> float {
         const int g = u % NG, tile = (u / NG) % ntile, rb = u / (NG * ntile);
         const bool with_rem = rem && rb == nrb - 1;                  // uniform
         rowbase = rb * CSC_TILE_ROWS;
@@ -2470,10 +2591,12 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
         const _Float16* tlo = lo_all + (size_t)tile * nslab * SLABF;
         float lmax;
         if (with_rem) {
-            gemm16x3_group<true>(th, tlo, g, tl->gs0[g], tl->gs1[g], rh, rl, R16T_CS, rowbase, ring, acc, accr);
+            if (screen) gemm16x1_group<true>(th, g, tl->gs0[g], tl->gs1[g], rh, R16T_CS, rowbase, ring, acc, accr);
+            else gemm16x3_group<true>(th, tlo, g, tl->gs0[g], tl->gs1[g], rh, rl, R16T_CS, rowbase, ring, acc, accr);
             lmax = group16x3_finish<true>(a, sl, tl, g, t, rowbase, permv, permr, acc, accr, lane_supp);
         } else {
-            gemm16x3_group<false>(th, tlo, g, tl->gs0[g], tl->gs1[g], rh, rl, R16T_CS, rowbase, ring, acc, accr);
+            if (screen) gemm16x1_group<false>(th, g, tl->gs0[g], tl->gs1[g], rh, R16T_CS, rowbase, ring, acc, accr);
+            else gemm16x3_group<false>(th, tlo, g, tl->gs0[g], tl->gs1[g], rh, rl, R16T_CS, rowbase, ring, acc, accr);
             lmax = group16x3_finish<false>(a, sl, tl, g, t, rowbase, permv, permr, acc, accr, lane_supp);
         }
         return lmax;
@@ -2494,51 +2617,57 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
         if (tid == 0) tl->cur_tile = tile;
         __syncthreads();
     };
-    // one unit of sweep 1: its maximum -> tcur (and tmax0 for the first sibling), running maximum
-    auto sweep_unit = [&](int u, int t, float& gmax) {
+    // the maximum of a unit over the workgroup (suppressed entries count as 0)
+    auto unit_max = [&](int u, int t, bool screen) -> float {
         tile_setup((u / NG) % ntile);
         bool lane_supp;
         int rowbase;
-        const float lmax = unit(u, t, lane_supp, rowbase);
+        const float lmax = unit(u, t, screen, lane_supp, rowbase);
         const float bv = wave_max(lane_supp ? fmaxf(lmax, 0.f) : lmax);
         if (lane == 63) sl->wmax[wave] = bv;
         __syncthreads();
-        const float m = fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
-        if (tid == 0) {
-            tl->tcur[u] = m;
-            if (t == 0) tl->tmax0[u] = m;
-        }
-        gmax = fmaxf(gmax, m);
+        return fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
     };
+    const float bandu = band / unscale;                              // the band in accumulator units
+    {
+        // ---- screen: the single-term maximum of every unit, + eps1 + eps3 = an upper bound of what the three-product
+        // sweep can find there; the units in descending order of that bound
+        const float e1 = (9.765625e-4f + 6.103515625e-05f + 1e-6f) * am + 2.98023223876953125e-08f * sqrtf((float)L) * (1.f + am);
+        const float slack = (e1 + 0.5f * band) / unscale;
+        for (int u = 0; u < nunits; ++u) {
+#ifdef CSC_PHASE_PROF
+            if (tid == 0) atomicAdd(&g_prof[4][blockIdx.x % PROF_BUCKETS], 1ull);
+#endif
+            const float m = unit_max(u, 0, true);
+            if (tid == 0) tl->tmax0[u] = m == m ? m + slack : INFINITY;      // (a NaN sorts first and is visited)
+        }
+        __syncthreads();
+        for (int u = tid; u < nunits; u += WG) {
+            const float v = tl->tmax0[u];
+            int rank = 0;
+            for (int w = 0; w < nunits; ++w) {
+                const float x = tl->tmax0[w];
+                rank += (x > v || (x == v && w < u)) ? 1 : 0;
+            }
+            tl->order[rank] = (short)u;
+        }
+    }
 
     for (int t = 0; t < nch; ++t) {
-        // ---- sweep 1: unit maxima (in accumulator units; the band is scaled to match) ----------------------
-        const float bandu = band / unscale;
+        // ---- sweep 1: three-product maxima of the units that can reach the band of the running maximum: by descending
+        // bound, the first few hold the maximum, and once a unit cannot reach the band no later one can
         float gmax = -INFINITY;                                       // workgroup-uniform
-        if (t == 0) {
-            for (int u = 0; u < nunits; ++u) sweep_unit(u, 0, gmax);
-            if (nch > 1) {
-                // the later siblings visit the units by descending unsuppressed maximum: the first few hold the new
-                // maximum, and once a unit cannot reach the band of the running maximum no later one can
-                __syncthreads();
-                for (int u = tid; u < nunits; u += WG) {
-                    const float v = tl->tmax0[u];
-                    int rank = 0;
-                    for (int w = 0; w < nunits; ++w) {
-                        const float x = tl->tmax0[w];
-                        rank += (x > v || (x == v && w < u)) ? 1 : 0;
-                    }
-                    tl->order[rank] = (short)u;
-                }
-            }
-        } else {
-            for (int u = tid; u < nunits; u += WG) tl->tcur[u] = -INFINITY;
-            __syncthreads();
-            for (int i = 0; i < nunits; ++i) {
-                const int u = tl->order[i];
-                if (fmaxf(tl->tmax0[u], 0.f) < gmax - bandu) break;   // cannot reach the band, nor can the rest (uniform)
-                sweep_unit(u, t, gmax);
-            }
+        for (int u = tid; u < nunits; u += WG) tl->tcur[u] = -INFINITY;
+        __syncthreads();
+        for (int i = 0; i < nunits; ++i) {
+            const int u = tl->order[i];
+            if ((t > 0 ? fmaxf(tl->tmax0[u], 0.f) : tl->tmax0[u]) < gmax - bandu) break;       // (uniform)
+#ifdef CSC_PHASE_PROF
+            if (tid == 0) atomicAdd(&g_prof[5][blockIdx.x % PROF_BUCKETS], 1ull);
+#endif
+            const float m = unit_max(u, t, false);
+            if (tid == 0) tl->tcur[u] = m;
+            gmax = fmaxf(gmax, m);
         }
         __syncthreads();
         // ---- sweep 2: candidates from the units that reach the band --------------------------------------
@@ -2553,10 +2682,13 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
         for (int u = 0; u < nunits; ++u) {
             if (!(tl->tcur[u] >= tau)) continue;                      // uniform
             const int g = u % NG;
+#ifdef CSC_PHASE_PROF
+            if (tid == 0) atomicAdd(&g_prof[6][blockIdx.x % PROF_BUCKETS], 1ull);
+#endif
             tile_setup((u / NG) % ntile);
             bool lane_supp;
             int rowbase;
-            const float lmax = unit(u, t, lane_supp, rowbase);
+            const float lmax = unit(u, t, false, lane_supp, rowbase);
             if (lmax >= tau) {
                 const int rowK = (rowbase + 64 * wave + 4 * lq) * K;
                 uint32_t mk[2] = {0u, 0u};
@@ -2977,6 +3109,20 @@ int csc_correlate(const float* d_bank32t, int K, int L, const double* d_signals,
     hipLaunchKernelGGL(correlate_kernel, dim3(B), dim3(WG), lds, (hipStream_t)stream, d_bank32t,
                        bank_meta(d_bank32t, K, L), K, L, Lp, d_signals, N, P, d_corr);
     return launch_status("correlate_kernel");
+}
+
+int csc_correlate64(const double* d_bank64, int K, int L, const double* d_signals, int B, int N, double* d_corr,
+                    void* stream) {
+    const int P = N - L + 1;
+    if (!d_bank64 || !d_signals || !d_corr || K <= 0 || L <= 0 || B < 0) FAIL(-1, "csc_correlate64: bad arguments");
+    if (P <= 0) FAIL(-6, "signal length %d shorter than atom length %d", N, L);
+    if ((size_t)L * 8 > 64 * 1024) FAIL(-8, "atom length %d exceeds the LDS window of csc_correlate64", L);
+    if (B > 65535) FAIL(-11, "csc_correlate64: at most 65535 signals per call");
+    if (B == 0) return 0;
+    clear_stale_error();
+    hipLaunchKernelGGL(correlate64_kernel, dim3(P, B), dim3(WG), (size_t)L * 8, (hipStream_t)stream, d_bank64, K, L,
+                       d_signals, N, P, d_corr);
+    return launch_status("correlate64_kernel");
 }
 
 int csc_tree_nodes(int max_sparsity, int connections, int branches, int* level_sizes) {

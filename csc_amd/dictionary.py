@@ -130,11 +130,15 @@ class CSCDictionary:
     # ------------------------------------------------------------------------------------------
     # convolutional operator (reference :380-484)
     # ------------------------------------------------------------------------------------------
-    def computeCorrelations(self, signal):
-        """(P, K) valid cross-correlations of ``signal`` with every atom (reference :395-407), on the
-        fp32 matrix cores; returned as float64 for API compatibility (fp32 accuracy)."""
-        c = self.device_bank().correlate(np.asarray(signal, dtype=np.float64)[None])
-        return c[0].double().cpu().numpy()
+    def computeCorrelations(self, signal, fast: bool = False):
+        """(P, K) valid cross-correlations of ``signal`` with every atom (reference :395-407).  Float64
+        arithmetic on the GPU by default (the reference's accuracy: callers such as the rmatvec of
+        getMaskedConvOperator rely on it); ``fast=True`` takes them on the fp32 matrix cores instead
+        (csc_correlate: fp32 accuracy, returned as float64)."""
+        sig = np.asarray(signal, dtype=np.float64)[None]
+        if fast:
+            return self.device_bank().correlate(sig)[0].double().cpu().numpy()
+        return self.device_bank().correlate64(sig)[0].cpu().numpy()
 
     def computeConvolutions(self, activations):
         """(N,) synthesis from a (P*K,) activation vector (reference :380-393).  Activations are

@@ -176,6 +176,19 @@ class DeviceBank:
                                               _ptr(out), _stream(self.device)), "csc_correlate")
         return out
 
+    def correlate64(self, signals) -> torch.Tensor:
+        """signals [B, N] -> device f64 [B, P, K]: float64 arithmetic throughout (csc_correlate64)."""
+        sig = self._to_device(signals)
+        B, N = sig.shape
+        P = N - self.L + 1
+        if P <= 0:
+            raise ValueError(f"signal length {N} shorter than atom length {self.L}")
+        with torch.cuda.device(self.device):
+            out = torch.empty((B, P, self.K), dtype=torch.float64, device=self.device)
+            _lib.check(self.lib.csc_correlate64(_ptr(self.bank64), self.K, self.L, _ptr(sig), B, N, _ptr(out),
+                                                _stream(self.device)), "csc_correlate64")
+        return out
+
     def _to_device(self, signals):
         if isinstance(signals, torch.Tensor):
             sig = signals.to(device=self.device, dtype=torch.float64)

@@ -66,6 +66,12 @@ int csc_similarity_table(const double* d_bank64, int K, int L, int N, double thr
 int csc_correlate(const float* d_bank32t, int K, int L, const double* d_signals, int B, int N,
                   float* d_corr, void* stream);
 
+/* The same correlations in float64 (fp64 FMA, no matrix cores): what the public computeCorrelations and the
+ * rmatvec of getMaskedConvOperator return (src/csc/dictionary.py:395-407, 409-425 are float64 arithmetic; a caller
+ * running its own lsqr on the operator relies on ~1e-12).  d_corr [B][P][K] f64; B <= 65535. */
+int csc_correlate64(const double* d_bank64, int K, int L, const double* d_signals, int B, int N, double* d_corr,
+                    void* stream);
+
 /* Tree shape of runMMPDF (src/csc/mmp.py:303-313, 388-424): level d (1..max_sparsity) holds
  * F_d = min(branches, connections^d) nodes; node j of level d has parent j mod connections^(d-1)
  * and sibling rank j div connections^(d-1).  Writes F_1..F_max into level_sizes[max_sparsity]

@@ -23,6 +23,7 @@ slabs = v[7]
 names = ["wait for the fragments (lgkmcnt)", "MFMA block 1 (issue)", "wait for the copies (vmcnt)", "barrier",
          "issue the copies", "MFMA block 2 (issue)", "request the next fragments", "MFMA block 3 (issue)"]
 tot = v[8:16].sum()
-print(f"{slabs:.0f} slabs, {tot / slabs:.0f} clocks per slab (wave 0)")
+print(f"{slabs:.0f} slabs, {tot / slabs:.0f} clocks per slab (wave 0); per signal: {slabs / n:.0f} slabs, units: "
+      f"sweep 1 first sibling {v[4] / n:.0f}, later siblings {v[5] / n:.0f}, sweep 2 {v[6] / n:.0f}; units within a single-term band of the maximum (first sibling): {v[3] / n:.1f}")
 for nme, x in zip(names, v[8:16]):
     print(f"  {nme:36s} {x / slabs:8.0f} clk/slab  {100 * x / tot:5.1f} %")

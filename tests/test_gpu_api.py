@@ -106,9 +106,22 @@ def test_true_positive_counts(dic, golden_signals):
 def test_compute_correlations_api(dic, golden_signals):
     z = np.load(os.path.join(H.ROOT, "tests", "golden", "rootcorr.npz"))
     sig = golden_signals["signals"][int(z["sig_idx"][0])]
+    # the public method is float64 arithmetic like the reference's (1e-12 against its FFT values); fast=True takes the
+    # same numbers on the fp32 matrix cores (fp32 accumulation over L = 492: 3e-6 ||signal||)
     c = dic.computeCorrelations(sig)
     assert c.shape == (247, 143) and c.dtype == np.float64
-    assert np.abs(c - z["corr"][0]).max() <= 3e-6 * np.linalg.norm(sig)
+    assert np.abs(c - z["corr"][0]).max() <= 1e-12 * np.linalg.norm(sig)
+    cf = dic.computeCorrelations(sig, fast=True)
+    assert cf.shape == (247, 143) and np.abs(cf - z["corr"][0]).max() <= 3e-6 * np.linalg.norm(sig)
+    # the masked operator a caller may hand to its own solver (reference :409-425): lsqr on it reproduces the
+    # projection of the engine, residual orthogonal to the selected atoms to float64 accuracy
+    from scipy.sparse.linalg import lsqr
+    mask = np.zeros(247 * 143)
+    mask[[10 * 143 + 5, 120 * 143 + 70]] = 1
+    op = dic.getMaskedConvOperator(mask)
+    x = lsqr(op, sig)[0]
+    approx, acts = dic.getSignalProjectionFromAtoms(sig, [dic._info(10, 5), dic._info(120, 70)])
+    assert np.allclose(x[mask > 0], acts[mask > 0], rtol=1e-9) and np.abs(op.rmatvec(sig - op @ x)[mask > 0]).max() < 1e-10
     # synthesis of a sparse activation vector = the placed atoms
     act = np.zeros(247 * 143)
     act[10 * 143 + 5], act[200 * 143 + 99] = 2.0, -1.0
