@@ -2177,7 +2177,8 @@ static __host__ __device__ inline int r16t_stride(int P, int Lp) {
 #define TG_BLK (2 * NG * BLKF)         // halves of one group-slab: 3 hi blocks, 3 lo blocks
 #define EPS3_ACC 1.220703125e-04f      // 2^-13
 
-#define MAX_UNITS16 1024               // (row block, bank tile, column group) units per node: K up to 49 152 at P <= 272
+#define MAX_UNITS16 1024               // (row block, bank tile, column group) units per node, and at most 2048 16-column
+                                       // blocks in the bank: K up to 32 768 at P <= 272
 struct Tiled16Lds {
     float tmax0[MAX_UNITS16];      // unsuppressed unit maxima (first sibling's sweep)
     float tcur[MAX_UNITS16];       // unit maxima of the current sibling's sweep (-inf = skipped)
@@ -2433,6 +2434,138 @@ __device__ __forceinline__ void gemm16x1_group(const _Float16* __restrict__ hi, 
     __syncthreads();
 }
 
+// float <-> unsigned key with the same order (for LDS atomicMax on unit maxima)
+__device__ __forceinline__ unsigned fkey(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// The screen of a whole node, without a barrier: every wave works on its own -- wave w takes the 16-column blocks
+// q = w, w + 4, ... (q = block + 9 (bank tile + ntile * row block)) against ALL the row tiles of the row block (16, or 17
+// with the remainder tile), one MFMA per row tile and slab on one B fragment.  Nobody else in the workgroup needs that
+// fragment, so each wave streams its own blocks L2 -> LDS (global_load_lds, one 1 KiB fragment-major block per copy)
+// through a private ring of SCREEN_AHEAD slots, across block boundaries, and waits only for its own copies (vmcnt).
+// The A side is the Hankel window: slab s uses the fragments W(2 s) .. W(2 s + 16) (W(j) = window elements 16 j + ...),
+// i.e. the set moves on by two per slab -- twenty registers in rotation (period 10, the phases below), two
+// ds_read_b128 per slab and wave.  A block's maximum is folded into key[] of its (row block, tile, column group) unit
+// with an LDS atomicMax (keys from fkey, preset to fkey(-inf)); masks are arithmetic: rows >= P, and the
+// ntile * 144 - K padding columns, which the packed bank puts in front.
+#define SCREEN_AHEAD 6                 // ring slots per wave (4 x 6 KiB = the 24 KiB ring of the three-product loop)
+template <bool REM>
+__device__ __forceinline__ void screen_blocks16(const LevelArgs& a, const _Float16* __restrict__ hi_all, unsigned* key,
+                                                const unsigned short* brange, int ntile, int nslab, int nrb,
+                                                const _Float16* rh, int R16T_CS, _Float16* ring) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int P = a.P, npad = ntile * CSC_TILE_COLS - a.K;
+    const int nq = NT * ntile * nrb;
+    constexpr int MTW = REM ? 17 : 16;
+    _Float16* myring = ring + wave * (SCREEN_AHEAD * BLKF);
+    // slab range of block q: outside it the block is zero padding (brange[block + 9 tile] = s0 | s1 << 8, built by the caller)
+    auto block_range = [&](int q, int& s0, int& s1) {
+        const int pk = __builtin_amdgcn_readfirstlane((int)brange[q % (NT * ntile)]);
+        s0 = pk & 0xff;
+        s1 = pk >> 8;
+    };
+    // the wave's stream of B blocks: copy cursor
+    int cq = wave - 4, cs = 0, ce = 0, cslot = 0;
+    bool more = true;                                                // the cursor has not run out (uniform)
+    const _Float16* cb = hi_all;
+    auto cursor_copy = [&]() {
+        while (cs >= ce) {
+            cq += 4;
+            if (cq >= nq) { more = false; return; }
+            block_range(cq, cs, ce);
+            cb = hi_all + (size_t)((cq / NT) % ntile) * nslab * SLABF + (cq % NT) * BLKF + lane * 8;
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)(cb + (size_t)cs * SLABF), (lptr_t)(myring + cslot * BLKF), 16, 0, 0);
+        ++cs;
+        cslot = cslot == SCREEN_AHEAD - 1 ? 0 : cslot + 1;
+    };
+    WAIT_VM(0);
+#pragma unroll
+    for (int i = 0; i < SCREEN_AHEAD; ++i) cursor_copy();
+    f16x8 W[20], b[2];
+    f32x4 acc[MTW];
+#ifdef CSC_PHASE_PROF
+    unsigned t3acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t3last = T3_CLK();
+#endif
+    int slot = 0;                                                    // ring slot of the slab being multiplied
+    // the stream's first fragment (the later ones are read one slab ahead, in body)
+    if (more) WAIT_VM(SCREEN_AHEAD - 1); else WAIT_VM(0);
+    b[0] = *reinterpret_cast<const f16x8*>(myring + lane * 8);
+    const _Float16* pa = rh;
+    auto body = [&](auto phc, int s) {
+        constexpr int PH = decltype(phc)::value;
+        // outstanding here: the copies of the next SCREEN_AHEAD - 1 stream slabs; the oldest is the one read now
+        T3_STAMP(4);
+        if (more) WAIT_VM(SCREEN_AHEAD - 2); else WAIT_VM(0);
+        T3_STAMP(0);
+        const int nslot = slot == SCREEN_AHEAD - 1 ? 0 : slot + 1;
+        b[(PH + 1) & 1] = *reinterpret_cast<const f16x8*>(myring + nslot * BLKF + lane * 8);
+        W[(2 * PH + 18) % 20] = *reinterpret_cast<const f16x8*>(pa + 32 * s + 16 * 18);
+        W[(2 * PH + 19) % 20] = *reinterpret_cast<const f16x8*>(pa + 32 * s + 16 * 19);
+#pragma unroll
+        for (int mi = 0; mi < MTW; ++mi)
+            acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[(2 * PH + mi) % 20], b[PH & 1], acc[mi], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                           // the slot's fragment is in registers: refill it
+        T3_STAMP(2);
+        cursor_copy();
+        slot = nslot;
+        __builtin_amdgcn_sched_barrier(0);
+        T3_STAMP(3);
+#ifdef CSC_PHASE_PROF
+        ++t3acc[5];
+#endif
+    };
+    for (int q = wave; q < nq; q += 4) {
+        int s0, s1;
+        block_range(q, s0, s1);
+        const int blk = q % NT, tile = (q / NT) % ntile, rb = q / (NT * ntile);
+        const int rowbase = rb * CSC_TILE_ROWS;
+        const int rowlim = min(P, rowbase + CSC_TILE_ROWS + ((REM && rb == nrb - 1) ? 16 : 0));
+        const bool colok = tile * CSC_TILE_COLS + 16 * blk + lr >= npad;
+        const int prow = rowbase + 4 * lq;                           // + 16 mi + rg
+        float lmax = -INFINITY;
+        if (s0 >= s1) {
+            if (colok && prow < rowlim) lmax = 0.f;
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < MTW; ++mi) acc[mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            pa = rh + (lr & 7) * R16T_CS + rowbase + (lr & 8) + 8 * lq;
+#pragma unroll
+            for (int i = 0; i < 18; ++i) W[i] = *reinterpret_cast<const f16x8*>(pa + 32 * s0 + 16 * i);
+            int s = s0;
+            // a block ends at any phase; the fragment read ahead for the next block's first slab moves to b[0]
+#define SCREEN_STEP(PH) body(std::integral_constant<int, PH>{}, s); \
+            if (++s >= s1) { if (((PH) & 1) == 0) b[0] = b[1]; break; }
+            while (true) {
+                SCREEN_STEP(0) SCREEN_STEP(1) SCREEN_STEP(2) SCREEN_STEP(3) SCREEN_STEP(4)
+                SCREEN_STEP(5) SCREEN_STEP(6) SCREEN_STEP(7) SCREEN_STEP(8) SCREEN_STEP(9)
+            }
+#undef SCREEN_STEP
+            if (colok) {
+#pragma unroll
+                for (int mi = 0; mi < MTW; ++mi)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        lmax = fmaxf(lmax, prow + 16 * mi + rg < rowlim ? acc[mi][rg] : -INFINITY);
+            }
+        }
+        lmax = wave_max(lmax);
+        if (lane == 63) atomicMax(&key[blk / NG + NG * (tile + ntile * rb)], fkey(lmax == lmax ? lmax : INFINITY));
+    }
+    WAIT_VM(0);
+#ifdef CSC_PHASE_PROF
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_prof[26 + i][blockIdx.x % PROF_BUCKETS], (unsigned long long)t3acc[i]);
+#endif
+}
+
 // masking of the entries outside the matrix + suppression by the first t siblings (bits from the similarity table);
 // returns the lane's maximum over its unsuppressed entries (remainder tile included), lane_supp = it holds a
 // suppressed one
@@ -2577,6 +2710,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
         }
     }
     __syncthreads();
+    PROF_MARK(0);
     const _Float16* hi_all = reinterpret_cast<const _Float16*>(a.bank16);      // scaled tiles: hi, then lo
     const _Float16* lo_all = hi_all + (size_t)ntile * nslab * SLABF;
 
@@ -2634,12 +2768,36 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
         // sweep can find there; the units in descending order of that bound
         const float e1 = (9.765625e-4f + 6.103515625e-05f + 1e-6f) * am + 2.98023223876953125e-08f * sqrtf((float)L) * (1.f + am);
         const float slack = (e1 + 0.5f * band) / unscale;
+        unsigned* key = reinterpret_cast<unsigned*>(tl->tmax0);
+        for (int u = tid; u < nunits; u += WG) key[u] = fkey(-INFINITY);
+        // slab range of every 16-column block of the bank (s0 | s1 << 8) -> tcur's space (NT * ntile <= 2048, checked at launch)
+        unsigned short* brange = reinterpret_cast<unsigned short*>(tl->tcur);
+        for (int e = tid; e < NT * ntile; e += WG) {
+            const int32_t* mk = a.meta + (size_t)(e / NT) * META_INTS + CSC_TILE_COLS;
+            const int blk = e % NT;
+            int lo = nslab, hi = 0;
+            for (int q = 0; q < nslab; ++q)
+                if (((uint32_t)mk[q] >> blk) & 1u) { lo = min(lo, q); hi = q + 1; }
+            brange[e] = (unsigned short)(min(lo, hi) | (hi << 8));
+        }
+        __syncthreads();
+        if (rem) screen_blocks16<true>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring);
+        else screen_blocks16<false>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring);
+        __syncthreads();
+        if (tid == 0) tl->cur_tile = -1;
+#ifdef CSC_SCREEN_CHECK
+        __syncthreads();
         for (int u = 0; u < nunits; ++u) {
-#ifdef CSC_PHASE_PROF
-            if (tid == 0) atomicAdd(&g_prof[4][blockIdx.x % PROF_BUCKETS], 1ull);
-#endif
             const float m = unit_max(u, 0, true);
-            if (tid == 0) tl->tmax0[u] = m == m ? m + slack : INFINITY;      // (a NaN sorts first and is visited)
+            const float k = fkey_inv(key[u]);
+            if (tid == 0 && m != k && blockIdx.x < 64)
+                printf("block %d depth %d unit %d of %d: stream %g, unit %g\n", blockIdx.x, d, u, nunits, k, m);
+        }
+        __syncthreads();
+#endif
+        for (int u = tid; u < nunits; u += WG) {
+            const float m = fkey_inv(key[u]);
+            tl->tmax0[u] = m + slack;
         }
         __syncthreads();
         for (int u = tid; u < nunits; u += WG) {
@@ -2651,6 +2809,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
             }
             tl->order[rank] = (short)u;
         }
+        PROF_MARK(1);
     }
 
     for (int t = 0; t < nch; ++t) {
@@ -2670,6 +2829,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
             gmax = fmaxf(gmax, m);
         }
         __syncthreads();
+        PROF_MARK(2);
         // ---- sweep 2: candidates from the units that reach the band --------------------------------------
         const float tau = gmax - bandu;
         // the value 0 of suppressed entries inside the band, or no finite maximum: the fp32 kernel decides
@@ -2728,12 +2888,14 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
             if (tid == 0) { *flag = 1; if (a.stats) atomicAdd(&a.stats[3], 1); }
             return;
         }
+        PROF_MARK(3);
         rescore_and_choose(a, sl, r64, ncand_raw, false, d);
         const int jc = j + t * stride;
         const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
         if (tid == 0) { tl->sib_pos[t] = sl->sup_pos[d]; tl->sib_atom[t] = sl->sup_atom[d]; }
         child_solve_and_write(a, sl, r64, s, jc, cid, d, a.resid_out, false);
         __syncthreads();
+        PROF_MARK(9);
     }
 }
 
@@ -3198,7 +3360,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
     const size_t lds16 = (size_t)ceil4(N) * 8 + 2 * (size_t)R16_COPIES * r16t_stride(P, Lp) * 2 + (size_t)TRING * TG_BLK * 2 +
                          sizeof(NodeLds) + sizeof(Tiled16Lds);
     const bool tiled16 = tiled && !(flags & CSC_FLAG_FP32_ONLY) && node_flags && mode == 0 && L <= 682 &&
-                         lds16 <= 80 * 1024 && (long long)n_tiles(K) * nrb * NG <= MAX_UNITS16;
+                         lds16 <= 80 * 1024 && (long long)n_tiles(K) * nrb * NG <= MAX_UNITS16 && n_tiles(K) * NT <= 2 * MAX_UNITS16;
     clear_stale_error();
     if (tiled16) hipFuncSetAttribute((const void*)mmp_level_tiled16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds16);

@@ -27,3 +27,18 @@ print(f"{slabs:.0f} slabs, {tot / slabs:.0f} clocks per slab (wave 0); per signa
       f"sweep 1 first sibling {v[4] / n:.0f}, later siblings {v[5] / n:.0f}, sweep 2 {v[6] / n:.0f}; units within a single-term band of the maximum (first sibling): {v[3] / n:.1f}")
 for nme, x in zip(names, v[8:16]):
     print(f"  {nme:36s} {x / slabs:8.0f} clk/slab  {100 * x / tot:5.1f} %")
+
+names2 = ["prologue + fp16 copies", "screen + order", "sweep 1 (three-product)", "sweep 2 + candidates", "-", "rescore + choose",
+          "gram dots", "solve", "residual + write", "tail"]
+nodes = 13 * n
+tot2 = v[16:26].sum()
+print(f"phases, clocks per node (thread 0): total {tot2 / nodes:.0f}")
+for nme, x in zip(names2, v[16:26]):
+    print(f"  {nme:36s} {x / nodes:10.0f}  {100 * x / tot2:5.1f} %")
+
+sl = v[31]
+if sl:
+    print(f"screen (wave 0): {sl / nodes:.0f} slabs per node, clocks per slab:")
+    for nme, x in zip(["wait for the copy (vmcnt)", "-", "fragment requests + MFMA issue", "refill copy", "between slabs (block ends, prologues)"],
+                      v[26:31]):
+        print(f"  {nme:40s} {x / sl:8.0f}")
