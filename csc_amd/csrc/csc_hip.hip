@@ -2491,9 +2491,6 @@ __device__ __forceinline__ void screen_blocks16(const LevelArgs& a, const _Float
     for (int i = 0; i < SCREEN_AHEAD; ++i) cursor_copy();
     f16x8 W[20], b[2];
     f32x4 acc[MTW];
-#ifdef CSC_PHASE_PROF
-    unsigned t3acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t3last = T3_CLK();
-#endif
     int slot = 0;                                                    // ring slot of the slab being multiplied
     // the stream's first fragment (the later ones are read one slab ahead, in body)
     if (more) WAIT_VM(SCREEN_AHEAD - 1); else WAIT_VM(0);
@@ -2502,9 +2499,7 @@ __device__ __forceinline__ void screen_blocks16(const LevelArgs& a, const _Float
     auto body = [&](auto phc, int s) {
         constexpr int PH = decltype(phc)::value;
         // outstanding here: the copies of the next SCREEN_AHEAD - 1 stream slabs; the oldest is the one read now
-        T3_STAMP(4);
         if (more) WAIT_VM(SCREEN_AHEAD - 2); else WAIT_VM(0);
-        T3_STAMP(0);
         const int nslot = slot == SCREEN_AHEAD - 1 ? 0 : slot + 1;
         b[(PH + 1) & 1] = *reinterpret_cast<const f16x8*>(myring + nslot * BLKF + lane * 8);
         W[(2 * PH + 18) % 20] = *reinterpret_cast<const f16x8*>(pa + 32 * s + 16 * 18);
@@ -2513,14 +2508,9 @@ __device__ __forceinline__ void screen_blocks16(const LevelArgs& a, const _Float
         for (int mi = 0; mi < MTW; ++mi)
             acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[(2 * PH + mi) % 20], b[PH & 1], acc[mi], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);                           // the slot's fragment is in registers: refill it
-        T3_STAMP(2);
         cursor_copy();
         slot = nslot;
-        __builtin_amdgcn_sched_barrier(0);
-        T3_STAMP(3);
-#ifdef CSC_PHASE_PROF
-        ++t3acc[5];
-#endif
+
     };
     for (int q = wave; q < nq; q += 4) {
         int s0, s1;
@@ -2560,10 +2550,6 @@ __device__ __forceinline__ void screen_blocks16(const LevelArgs& a, const _Float
         if (lane == 63) atomicMax(&key[blk / NG + NG * (tile + ntile * rb)], fkey(lmax == lmax ? lmax : INFINITY));
     }
     WAIT_VM(0);
-#ifdef CSC_PHASE_PROF
-    if (threadIdx.x == 0)
-        for (int i = 0; i < 6; ++i) atomicAdd(&g_prof[26 + i][blockIdx.x % PROF_BUCKETS], (unsigned long long)t3acc[i]);
-#endif
 }
 
 // masking of the entries outside the matrix + suppression by the first t siblings (bits from the similarity table);

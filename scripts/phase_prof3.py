@@ -23,8 +23,8 @@ slabs = v[7]
 names = ["wait for the fragments (lgkmcnt)", "MFMA block 1 (issue)", "wait for the copies (vmcnt)", "barrier",
          "issue the copies", "MFMA block 2 (issue)", "request the next fragments", "MFMA block 3 (issue)"]
 tot = v[8:16].sum()
-print(f"{slabs:.0f} slabs, {tot / slabs:.0f} clocks per slab (wave 0); per signal: {slabs / n:.0f} slabs, units: "
-      f"sweep 1 first sibling {v[4] / n:.0f}, later siblings {v[5] / n:.0f}, sweep 2 {v[6] / n:.0f}; units within a single-term band of the maximum (first sibling): {v[3] / n:.1f}")
+print(f"{slabs:.0f} slabs, {tot / slabs:.0f} clocks per slab (wave 0); per signal: {slabs / n:.0f} slabs, three-product units: "
+      f"sweep 1 {v[5] / n:.0f}, sweep 2 {v[6] / n:.0f}")
 for nme, x in zip(names, v[8:16]):
     print(f"  {nme:36s} {x / slabs:8.0f} clk/slab  {100 * x / tot:5.1f} %")
 
@@ -36,9 +36,3 @@ print(f"phases, clocks per node (thread 0): total {tot2 / nodes:.0f}")
 for nme, x in zip(names2, v[16:26]):
     print(f"  {nme:36s} {x / nodes:10.0f}  {100 * x / tot2:5.1f} %")
 
-sl = v[31]
-if sl:
-    print(f"screen (wave 0): {sl / nodes:.0f} slabs per node, clocks per slab:")
-    for nme, x in zip(["wait for the copy (vmcnt)", "-", "fragment requests + MFMA issue", "refill copy", "between slabs (block ends, prologues)"],
-                      v[26:31]):
-        print(f"  {nme:40s} {x / sl:8.0f}")

@@ -119,3 +119,35 @@ if os.path.isdir(src3):
     json.dump(summary3, open(os.path.join(dst, f"{tag}_config3_pmc_summary.json"), "w"), indent=1)
     print("config 3:", {k: v.get("mfma_busy_fraction_of_simd_cycles") for k, v in summary3["per_kernel"].items()},
           summary3.get("run"))
+
+# ---- L2 view and instruction mix (scripts/profile_config3_l2.sh, profile_config3_sq.sh, profile_config2_sq.sh) ----
+def per_kernel_totals(path, kernels):
+    acc, n = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(int))
+    for row in csv.DictReader(open(path)):
+        k = next((k for k in kernels if row["Kernel_Name"].startswith(k + "(") or row["Kernel_Name"] == k), None)
+        if k is None:
+            continue
+        acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        n[k][row["Counter_Name"]] += 1
+    return {k: {c: {"sum": v, "launches": n[k][c]} for c, v in d.items()} for k, d in acc.items()}
+
+
+extra = {}
+for name, sub, groups, kernels in (
+        ("config3_l2", f"prof3l2_{tag}", ("pmc_fetch", "pmc_tcc", "pmc_tcp"), ("mmp_level_tiled16_kernel",)),
+        ("config3_instruction_mix", f"prof3sq_{tag}", ("pmc_a", "pmc_b"), ("mmp_level_tiled16_kernel",)),
+        ("config2_instruction_mix", f"prof2sq_{tag}", ("pmc_a", "pmc_b"), ("mmp_level_lean_kernel", "mmp_level_kernel"))):
+    d = {}
+    for g in groups:
+        f = glob.glob(os.path.join(ROOT, "gpurun_out", sub, g, "*counter_collection.csv"))
+        if f:
+            for k, v in per_kernel_totals(f[0], kernels).items():
+                d.setdefault(k, {}).update(v)
+    if d:
+        extra[name] = d
+if extra:
+    extra["note"] = ("sums over all launches of the run (config 3: run_config3.py 2048 2 = 3 solves x 5 levels; config 2: bench.py "
+                     "--steps 10 --warmup 2 and its set-up calls); SQ_*_CYCLES and SQ_WAIT_* / SQ_ACTIVE_* are in units of 4 clocks; "
+                     "FETCH_SIZE in KiB before the gfx950 x2 correction")
+    json.dump(extra, open(os.path.join(dst, f"{tag}_pmc_extra.json"), "w"), indent=1)
+    print("extra:", list(extra))
