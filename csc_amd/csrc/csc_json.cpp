@@ -6,13 +6,21 @@
 // device records (one contiguous record per signal, CSC_FLAG_RECORDS_AOS), formatting floats like Python's
 // float.__repr__ (shortest round-trip digits; fixed notation for 1e-4 <= |x| < 1e16, else d.ddde-XX) and reusing
 // one pre-formatted block per dictionary atom.
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
 #include <charconv>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <unistd.h>
 
 #include "../../include/csc_hip.h"
 
@@ -78,24 +86,66 @@ inline char* put_int(char* out, long long v) {
     return r.ptr;
 }
 
-struct Sink {
-    FILE* f;
-    std::vector<char> buf;
-    size_t n = 0;
-    bool ok = true;
-    explicit Sink(FILE* file) : f(file), buf(4u << 20) {}
-    char* room(size_t need) {
-        if (n + need > buf.size()) flush();
-        return buf.data() + n;
-    }
-    void advance(char* end) { n = (size_t)(end - buf.data()); }
-    void put(const char* s, size_t len) { char* p = room(len); memcpy(p, s, len); n += len; }
-    void put(const std::string& s) { put(s.data(), s.size()); }
-    void flush() {
-        if (n && fwrite(buf.data(), 1, n, f) != n) ok = false;
-        n = 0;
+// everything of a record that does not depend on the record: indentation, keys, one tail per dictionary atom
+struct Formatter {
+    int K, connections, n_atoms;
+    const char* records;
+    const int64_t* ids;
+    const double* snr;
+    const uint8_t* snr_is_int;
+    size_t rec_bytes, max_bytes;
+    std::vector<std::string> atom_tail;
+    std::string open_sig, snr_key, results_key, open_res, path_key, atoms_key, open_atom, delay_line, close_sig;
+
+    // record s at p (followed by ",\n" unless it is the last of the list); nullptr = an atom index outside the dictionary
+    char* record(char* p, int64_t s, bool last) const {
+        const char* rec = records + (size_t)s * rec_bytes;
+        const double* mse = reinterpret_cast<const double*>(rec);
+        const int32_t* leaf = reinterpret_cast<const int32_t*>(rec + 8 * (size_t)K);
+        const int32_t* sel = reinterpret_cast<const int32_t*>(rec + 16 * (size_t)K);
+        memcpy(p, open_sig.data(), open_sig.size()); p += open_sig.size();
+        p = put_int(p, ids[s]);
+        memcpy(p, snr_key.data(), snr_key.size()); p += snr_key.size();
+        if (snr_is_int && snr_is_int[s]) p = put_int(p, (long long)snr[s]);
+        else p = py_float_repr(p, snr[s]);
+        memcpy(p, results_key.data(), results_key.size()); p += results_key.size();
+        for (int k = 1; k <= K; ++k) {
+            memcpy(p, open_res.data(), open_res.size()); p += open_res.size();
+            p = py_float_repr(p, mse[k - 1]);
+            memcpy(p, path_key.data(), path_key.size()); p += path_key.size();
+            int j = leaf[2 * (k - 1)];                                // the '<=' (last minimum) leaf
+            for (int e = 0; e < k; ++e) {                             // base-c digits, least significant first, + 1
+                if (e) *p++ = '-';
+                p = put_int(p, j % connections + 1);
+                j /= connections;
+            }
+            memcpy(p, atoms_key.data(), atoms_key.size()); p += atoms_key.size();
+            for (int e = 0; e < k; ++e) {
+                const int32_t pos = sel[((size_t)(k - 1) * K + e) * 2], atom = sel[((size_t)(k - 1) * K + e) * 2 + 1];
+                if (atom < 0 || atom >= n_atoms) return nullptr;
+                if (e) { *p++ = ','; *p++ = '\n'; }
+                memcpy(p, open_atom.data(), open_atom.size()); p += open_atom.size();
+                p = put_int(p, pos);
+                const std::string& t = atom_tail[atom];
+                memcpy(p, t.data(), t.size()); p += t.size();
+            }
+            memcpy(p, delay_line.data(), delay_line.size()); p += delay_line.size();
+            if (k < K) { *p++ = ','; *p++ = '\n'; }
+        }
+        memcpy(p, close_sig.data(), close_sig.size()); p += close_sig.size();
+        if (!last) { *p++ = ','; *p++ = '\n'; }
+        return p;
     }
 };
+
+bool write_all(int fd, const char* buf, size_t n, off_t off) {
+    while (n) {
+        const ssize_t w = pwrite(fd, buf, n, off);
+        if (w < 0) { if (errno == EINTR) continue; return false; }
+        buf += w; n -= (size_t)w; off += w;
+    }
+    return true;
+}
 
 thread_local char g_json_err[256] = "";
 
@@ -124,17 +174,24 @@ int csc_sparvar_json_write(const char* path, int append, const void* records, in
     if (!path || (S > 0 && (!records || !ids || !snr)) || K < 1 || K > CSC_MAX_SPARSITY || connections < 1 ||
         !atom_b || !atom_y || !atom_s || n_atoms < 1 || indent_level < 0 || indent_level > 8)
         JFAIL(-1, "csc_sparvar_json_write: bad arguments");
-    FILE* f = fopen(path, append ? "ab" : "wb");
-    if (!f) JFAIL(-2, "csc_sparvar_json_write: cannot open %s", path);
-    Sink out(f);
+    const int fd = open(path, O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0644);
+    if (fd < 0) JFAIL(-2, "csc_sparvar_json_write: cannot open %s", path);
+    off_t off = append ? lseek(fd, 0, SEEK_END) : 0;
+    if (off < 0) { close(fd); JFAIL(-2, "csc_sparvar_json_write: cannot seek in %s", path); }
     // indentation strings: the list sits at `indent_level` (its '[' follows the key on the caller's line)
     auto ind = [&](int extra) { return std::string(4 * (size_t)(indent_level + extra), ' '); };
     const std::string i1 = ind(1), i2 = ind(2), i3 = ind(3), i4 = ind(4), i5 = ind(5), i6 = ind(6), i0 = ind(0);
+    Formatter F;
+    F.K = K; F.connections = connections; F.n_atoms = n_atoms;
+    F.records = static_cast<const char*>(records); F.ids = ids; F.snr = snr; F.snr_is_int = snr_is_int;
+    F.rec_bytes = (size_t)K * (16 + 8 * (size_t)K);
+    // worst case of one signal entry: K results x (K atoms x (~60 + tail) + ~200)
+    F.max_bytes = 512 + (size_t)K * (256 + 24 * (size_t)K + (size_t)K * (96 + 3 * 32 + 8 * 4 * 7));
     // one pre-formatted tail per atom: ,\n"b": ..,\n"y": ..,\n"s": ..\n}   (everything after the "x" line)
-    std::vector<std::string> atom_tail((size_t)n_atoms);
+    F.atom_tail.resize((size_t)n_atoms);
     char num[48];
     for (int k = 0; k < n_atoms; ++k) {
-        std::string& t = atom_tail[k];
+        std::string& t = F.atom_tail[k];
         t = ",\n" + i6 + "\"b\": ";
         t.append(num, py_float_repr(num, atom_b[k]) - num);
         t += ",\n" + i6 + "\"y\": ";
@@ -143,75 +200,76 @@ int csc_sparvar_json_write(const char* path, int append, const void* records, in
         t.append(num, py_float_repr(num, atom_s[k]) - num);
         t += "\n" + i5 + "}";
     }
-    std::string delay_line = "\n" + i4 + "],\n" + i4 + "\"delay\": ";
-    delay_line.append(num, py_float_repr(num, delay) - num);
-    delay_line += "\n" + i3 + "}";
-    const std::string open_sig = i1 + "{\n" + i2 + "\"id\": ";
-    const std::string snr_key = ",\n" + i2 + "\"snr\": ";
-    const std::string results_key = ",\n" + i2 + "\"results\": [\n";
-    const std::string open_res = i3 + "{\n" + i4 + "\"mse\": ";
-    const std::string path_key = ",\n" + i4 + "\"path\": \"";
-    const std::string atoms_key = "\",\n" + i4 + "\"atoms\": [\n";
-    const std::string open_atom = i5 + "{\n" + i6 + "\"x\": ";
-    const std::string close_sig = "\n" + i2 + "]\n" + i1 + "}";
-    const size_t rec_bytes = (size_t)K * (16 + 8 * (size_t)K);
+    F.delay_line = "\n" + i4 + "],\n" + i4 + "\"delay\": ";
+    F.delay_line.append(num, py_float_repr(num, delay) - num);
+    F.delay_line += "\n" + i3 + "}";
+    F.open_sig = i1 + "{\n" + i2 + "\"id\": ";
+    F.snr_key = ",\n" + i2 + "\"snr\": ";
+    F.results_key = ",\n" + i2 + "\"results\": [\n";
+    F.open_res = i3 + "{\n" + i4 + "\"mse\": ";
+    F.path_key = ",\n" + i4 + "\"path\": \"";
+    F.atoms_key = "\",\n" + i4 + "\"atoms\": [\n";
+    F.open_atom = i5 + "{\n" + i6 + "\"x\": ";
+    F.close_sig = "\n" + i2 + "]\n" + i1 + "}";
+
+    bool ok = true;
+    int64_t bad_record = -1;
+    auto put = [&](const std::string& t) { ok = ok && write_all(fd, t.data(), t.size(), off); off += (off_t)t.size(); };
+    // formatting runs at ~1 M records/s per core and the page cache takes ~2 GB/s per writer, so large lists are cut
+    // into chunks that threads format into buffers of their own and write at their own offsets (pwrite)
+    int T = 1;
+    if (S >= 8192) {
+        T = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+        if (const char* e = getenv("CSC_JSON_THREADS")) T = std::max(1, std::min(64, atoi(e)));
+    }
     if (S == 0) {
-        out.put("[]", 2);
+        put("[]");
     } else {
-        out.put("[\n", 2);
-        for (int64_t s = 0; s < S; ++s) {
-            const char* rec = static_cast<const char*>(records) + (size_t)s * rec_bytes;
-            const double* mse = reinterpret_cast<const double*>(rec);
-            const int32_t* leaf = reinterpret_cast<const int32_t*>(rec + 8 * (size_t)K);
-            const int32_t* sel = reinterpret_cast<const int32_t*>(rec + 16 * (size_t)K);
-            // worst case of one signal entry: K results x (K atoms x (~60 + tail) + ~200)
-            char* p = out.room(512 + (size_t)K * (256 + 24 * (size_t)K + (size_t)K * (96 + 3 * 32 + 8 * 4 * 7)));
-            memcpy(p, open_sig.data(), open_sig.size()); p += open_sig.size();
-            p = put_int(p, ids[s]);
-            memcpy(p, snr_key.data(), snr_key.size()); p += snr_key.size();
-            if (snr_is_int && snr_is_int[s]) p = put_int(p, (long long)snr[s]);
-            else p = py_float_repr(p, snr[s]);
-            memcpy(p, results_key.data(), results_key.size()); p += results_key.size();
-            for (int k = 1; k <= K; ++k) {
-                memcpy(p, open_res.data(), open_res.size()); p += open_res.size();
-                p = py_float_repr(p, mse[k - 1]);
-                memcpy(p, path_key.data(), path_key.size()); p += path_key.size();
-                int j = leaf[2 * (k - 1)];                            // the '<=' (last minimum) leaf
-                for (int e = 0; e < k; ++e) {                         // base-c digits, least significant first, + 1
-                    if (e) *p++ = '-';
-                    p = put_int(p, j % connections + 1);
-                    j /= connections;
+        put("[\n");
+        const int64_t chunk = T > 1 ? 1024 : 512;                    // records per buffer
+        std::vector<std::vector<char>> buf((size_t)T);
+        for (auto& b : buf) b.resize((size_t)chunk * F.max_bytes);
+        std::vector<size_t> len((size_t)T);
+        std::atomic<int64_t> bad{-1};
+        for (int64_t r0 = 0; r0 < S && ok && bad.load() < 0; r0 += chunk * T) {
+            auto format = [&](int t) {
+                const int64_t a = std::min(S, r0 + (int64_t)t * chunk), b = std::min(S, a + chunk);
+                char* p = buf[t].data();
+                for (int64_t s = a; s < b; ++s) {
+                    char* q = F.record(p, s, s + 1 == S);
+                    if (!q) { bad.store(s); break; }
+                    p = q;
                 }
-                memcpy(p, atoms_key.data(), atoms_key.size()); p += atoms_key.size();
-                for (int e = 0; e < k; ++e) {
-                    const int32_t pos = sel[((size_t)(k - 1) * K + e) * 2], atom = sel[((size_t)(k - 1) * K + e) * 2 + 1];
-                    if (atom < 0 || atom >= n_atoms) { fclose(f); JFAIL(-3, "record %lld: atom index %d outside the dictionary", (long long)s, atom); }
-                    if (e) { *p++ = ','; *p++ = '\n'; }
-                    memcpy(p, open_atom.data(), open_atom.size()); p += open_atom.size();
-                    p = put_int(p, pos);
-                    const std::string& t = atom_tail[atom];
-                    memcpy(p, t.data(), t.size()); p += t.size();
-                }
-                memcpy(p, delay_line.data(), delay_line.size()); p += delay_line.size();
-                if (k < K) { *p++ = ','; *p++ = '\n'; }
+                len[t] = (size_t)(p - buf[t].data());
+            };
+            std::vector<off_t> at((size_t)T);
+            std::atomic<bool> wok{true};
+            auto flush = [&](int t) { if (len[t] && !write_all(fd, buf[t].data(), len[t], at[t])) wok.store(false); };
+            if (T == 1) {
+                format(0);
+                at[0] = off;
+                if (bad.load() < 0) flush(0);
+                off += (off_t)len[0];
+            } else {
+                std::vector<std::thread> th;
+                for (int t = 0; t < T; ++t) th.emplace_back(format, t);
+                for (auto& x : th) x.join();
+                if (bad.load() >= 0) break;
+                for (int t = 0; t < T; ++t) { at[t] = off; off += (off_t)len[t]; }
+                th.clear();
+                for (int t = 0; t < T; ++t) th.emplace_back(flush, t);
+                for (auto& x : th) x.join();
             }
-            memcpy(p, close_sig.data(), close_sig.size()); p += close_sig.size();
-            if (s + 1 < S) { *p++ = ','; *p++ = '\n'; }
-            out.advance(p);
+            ok = ok && wok.load();
         }
-        out.put("\n", 1);
-        out.put(i0);
-        out.put("]", 1);
+        bad_record = bad.load();
+        if (bad_record < 0) put("\n" + i0 + "]");
     }
-    if (close_object) {                                               // the enclosing dict(s) of the caller's header
-        for (int lv = indent_level - 1; lv >= 0; --lv) {
-            out.put("\n", 1);
-            out.put(std::string(4 * (size_t)lv, ' '));
-            out.put("}", 1);
-        }
+    if (bad_record < 0 && close_object) {                             // the enclosing dict(s) of the caller's header
+        for (int lv = indent_level - 1; lv >= 0; --lv) put("\n" + std::string(4 * (size_t)lv, ' ') + "}");
     }
-    out.flush();
-    const bool ok = out.ok && fclose(f) == 0;
+    ok = (close(fd) == 0) && ok;
+    if (bad_record >= 0) JFAIL(-3, "record %lld: atom index outside the dictionary", (long long)bad_record);
     if (!ok) JFAIL(-4, "csc_sparvar_json_write: write to %s failed", path);
     return 0;
 #undef JFAIL

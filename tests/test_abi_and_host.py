@@ -185,3 +185,50 @@ def test_torch_custom_ops_registered_with_shape_inference():
     from csc_amd import _lib
     assert b32.shape == (_lib.lib().csc_bank32_elems(143, 492),) and sim.shape == (143 * 143 * 16,)
     assert pos.shape == atom.shape == mse.shape == (10, 15) and rec.shape == (10, 280) and rec.dtype == torch.uint8
+
+
+def test_json_writer_threads_write_the_same_bytes(tmp_path, monkeypatch):
+    """Lists of >= 8192 records are formatted by several threads, each chunk written at its own offset: the file must be
+    the one a single thread writes (and the one json.loads reads back), in append mode too; a record that names an atom
+    outside the dictionary fails the call with -3."""
+    import ctypes as C
+    import json
+    from csc_amd import _lib
+    lib = _lib.lib()
+    S, K, c, A = 20011, 5, 3, 143
+    rng = np.random.default_rng(4)
+    rec = np.zeros((S, K * (16 + 8 * K)), dtype=np.uint8)
+    mse = rng.random((S, K)) * 10.0 ** rng.integers(-8, 3, (S, K))
+    leaf = rng.integers(0, 3, (S, K, 2)).astype(np.int32)
+    sel = np.zeros((S, K, K, 2), dtype=np.int32)
+    sel[..., 0] = rng.integers(0, 247, (S, K, K))
+    sel[..., 1] = rng.integers(0, A, (S, K, K))
+    rec[:, :8 * K] = mse.view(np.uint8).reshape(S, -1)
+    rec[:, 8 * K:16 * K] = leaf.view(np.uint8).reshape(S, -1)
+    rec[:, 16 * K:] = sel.view(np.uint8).reshape(S, -1)
+    ids = np.arange(S, dtype=np.int64)[::-1].copy()
+    snr = rng.integers(0, 16, S).astype(np.float64)
+    isint = (rng.random(S) < 0.5).astype(np.uint8)
+    b, y, s_ = rng.random(A), rng.random(A), np.ones(A)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+
+    def write(path, threads, append=0, records=rec):
+        monkeypatch.setenv("CSC_JSON_THREADS", str(threads))
+        return lib.csc_sparvar_json_write(str(path).encode(), append, p(records), S, K, c, p(ids), p(snr), p(isint),
+                                          C.c_double(0.25), p(b), p(y), p(s_), A, 1, 1)
+
+    one, many = tmp_path / "one.json", tmp_path / "many.json"
+    assert write(one, 1) == 0 and write(many, 5) == 0
+    data = open(one, "rb").read()
+    assert data == open(many, "rb").read()
+    got = json.loads(b'{"mmp": ' + data)["mmp"]
+    assert len(got) == S and got[0]["id"] == S - 1 and got[-1]["results"][4]["mse"] == mse[-1, 4]
+    assert [a["x"] for a in got[7]["results"][2]["atoms"]] == sel[7, 2, :3, 0].tolist()
+    head = b'{\n    "mmp": '
+    open(many, "wb").write(head)
+    assert write(many, 3, append=1) == 0
+    assert open(many, "rb").read() == head + data
+    bad = rec.copy()
+    bad[S - 5, 16 * K + 4:16 * K + 8] = np.array([A], dtype=np.int32).view(np.uint8)
+    assert write(tmp_path / "bad.json", 4, records=bad) == -3
+    assert b"outside the dictionary" in lib.csc_json_last_error()
