@@ -2335,6 +2335,9 @@ __device__ __forceinline__ void gemm16x3_group(const _Float16* __restrict__ hi, 
     __syncthreads();
 }
 
+#ifdef CSC_SCREEN_CHECK
+// Development aid (-DCSC_SCREEN_CHECK): the screen of ONE unit through the workgroup ring of the three-product loop; the level
+// kernel then prints every unit whose maximum differs from what screen_blocks16 found.
 // The screen of a unit: the hi x hi product alone (one MFMA per tile and slab instead of three), good to
 //     eps1 = (2^-10 + 2^-14 + 1e-6) am + 2^-25 sqrt(L) (1 + am)
 // like the single-term filter of the untiled kernels (two operand roundings of 2^-11 each, fp32 accumulation of L <= 682
@@ -2433,6 +2436,7 @@ __device__ __forceinline__ void gemm16x1_group(const _Float16* __restrict__ hi, 
 #undef T1_MFMA
     __syncthreads();
 }
+#endif
 
 // float <-> unsigned key with the same order (for LDS atomicMax on unit maxima)
 __device__ __forceinline__ unsigned fkey(float f) {
@@ -2462,25 +2466,32 @@ __device__ __forceinline__ void screen_blocks16(const LevelArgs& a, const _Float
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int P = a.P, npad = ntile * CSC_TILE_COLS - a.K;
-    const int nq = NT * ntile * nrb;
     constexpr int MTW = REM ? 17 : 16;
     _Float16* myring = ring + wave * (SCREEN_AHEAD * BLKF);
-    // slab range of block q: outside it the block is zero padding (brange[block + 9 tile] = s0 | s1 << 8, built by the caller)
-    auto block_range = [&](int q, int& s0, int& s1) {
-        const int pk = __builtin_amdgcn_readfirstlane((int)brange[q % (NT * ntile)]);
+    // block position (block of the tile, tile, row block), moved on by the wave's stride of four blocks
+    struct Pos { int blk, tile, rb; };
+    auto advance = [&](Pos& p) {
+        p.blk += 4;
+        if (p.blk >= NT) { p.blk -= NT; if (++p.tile == ntile) { p.tile = 0; ++p.rb; } }
+    };
+    // slab range of a block: outside it the block is zero padding (brange[block + 9 tile] = s0 | s1 << 8, built by the caller)
+    auto block_range = [&](const Pos& p, int& s0, int& s1) {
+        const int pk = __builtin_amdgcn_readfirstlane((int)brange[p.blk + NT * p.tile]);
         s0 = pk & 0xff;
         s1 = pk >> 8;
     };
-    // the wave's stream of B blocks: copy cursor
-    int cq = wave - 4, cs = 0, ce = 0, cslot = 0;
+    // the wave's stream of B blocks: copy cursor (starts one stride before the wave's first block)
+    Pos cp = {wave - 4, 0, 0};
+    int cs = 0, ce = 0, cslot = 0;
     bool more = true;                                                // the cursor has not run out (uniform)
     const _Float16* cb = hi_all;
     auto cursor_copy = [&]() {
         while (cs >= ce) {
-            cq += 4;
-            if (cq >= nq) { more = false; return; }
-            block_range(cq, cs, ce);
-            cb = hi_all + (size_t)((cq / NT) % ntile) * nslab * SLABF + (cq % NT) * BLKF + lane * 8;
+            if (!more) return;
+            advance(cp);
+            if (cp.rb >= nrb) { more = false; return; }
+            block_range(cp, cs, ce);
+            cb = hi_all + (size_t)cp.tile * nslab * SLABF + cp.blk * BLKF + lane * 8;
         }
         __builtin_amdgcn_global_load_lds((gptr_t)(cb + (size_t)cs * SLABF), (lptr_t)(myring + cslot * BLKF), 16, 0, 0);
         ++cs;
@@ -2496,8 +2507,10 @@ __device__ __forceinline__ void screen_blocks16(const LevelArgs& a, const _Float
     if (more) WAIT_VM(SCREEN_AHEAD - 1); else WAIT_VM(0);
     b[0] = *reinterpret_cast<const f16x8*>(myring + lane * 8);
     const _Float16* pa = rh;
-    auto body = [&](auto phc, int s) {
+    // one slab; FIRST: the block's first slab starts the accumulators from zero (an inline-constant C operand)
+    auto body = [&](auto phc, auto firstc, int s) {
         constexpr int PH = decltype(phc)::value;
+        constexpr bool FIRST = decltype(firstc)::value;
         // outstanding here: the copies of the next SCREEN_AHEAD - 1 stream slabs; the oldest is the one read now
         if (more) WAIT_VM(SCREEN_AHEAD - 2); else WAIT_VM(0);
         const int nslot = slot == SCREEN_AHEAD - 1 ? 0 : slot + 1;
@@ -2506,48 +2519,60 @@ __device__ __forceinline__ void screen_blocks16(const LevelArgs& a, const _Float
         W[(2 * PH + 19) % 20] = *reinterpret_cast<const f16x8*>(pa + 32 * s + 16 * 19);
 #pragma unroll
         for (int mi = 0; mi < MTW; ++mi)
-            acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[(2 * PH + mi) % 20], b[PH & 1], acc[mi], 0, 0, 0);
+            acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[(2 * PH + mi) % 20], b[PH & 1],
+                                                             FIRST ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mi], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);                           // the slot's fragment is in registers: refill it
         cursor_copy();
         slot = nslot;
-
     };
-    for (int q = wave; q < nq; q += 4) {
+    Pos p = {wave, 0, 0};
+    for (; p.rb < nrb; advance(p)) {
         int s0, s1;
-        block_range(q, s0, s1);
-        const int blk = q % NT, tile = (q / NT) % ntile, rb = q / (NT * ntile);
-        const int rowbase = rb * CSC_TILE_ROWS;
-        const int rowlim = min(P, rowbase + CSC_TILE_ROWS + ((REM && rb == nrb - 1) ? 16 : 0));
-        const bool colok = tile * CSC_TILE_COLS + 16 * blk + lr >= npad;
-        const int prow = rowbase + 4 * lq;                           // + 16 mi + rg
+        block_range(p, s0, s1);
+        const int rowbase = p.rb * CSC_TILE_ROWS;
+        const int rows = min(P - rowbase, CSC_TILE_ROWS + ((REM && p.rb == nrb - 1) ? 16 : 0));   // valid rows of the block
+        const bool colok = p.tile * CSC_TILE_COLS + 16 * p.blk + lr >= npad;
         float lmax = -INFINITY;
         if (s0 >= s1) {
-            if (colok && prow < rowlim) lmax = 0.f;
+            if (4 * lq < rows) lmax = 0.f;
         } else {
-#pragma unroll
-            for (int mi = 0; mi < MTW; ++mi) acc[mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
             pa = rh + (lr & 7) * R16T_CS + rowbase + (lr & 8) + 8 * lq;
 #pragma unroll
             for (int i = 0; i < 18; ++i) W[i] = *reinterpret_cast<const f16x8*>(pa + 32 * s0 + 16 * i);
             int s = s0;
             // a block ends at any phase; the fragment read ahead for the next block's first slab moves to b[0]
-#define SCREEN_STEP(PH) body(std::integral_constant<int, PH>{}, s); \
+#define SCREEN_STEP(PH) body(std::integral_constant<int, PH>{}, std::false_type{}, s); \
             if (++s >= s1) { if (((PH) & 1) == 0) b[0] = b[1]; break; }
-            while (true) {
-                SCREEN_STEP(0) SCREEN_STEP(1) SCREEN_STEP(2) SCREEN_STEP(3) SCREEN_STEP(4)
-                SCREEN_STEP(5) SCREEN_STEP(6) SCREEN_STEP(7) SCREEN_STEP(8) SCREEN_STEP(9)
+            body(std::integral_constant<int, 0>{}, std::true_type{}, s);
+            if (++s >= s1) {
+                b[0] = b[1];
+            } else {
+                while (true) {
+                    SCREEN_STEP(1) SCREEN_STEP(2) SCREEN_STEP(3) SCREEN_STEP(4) SCREEN_STEP(5)
+                    SCREEN_STEP(6) SCREEN_STEP(7) SCREEN_STEP(8) SCREEN_STEP(9) SCREEN_STEP(0)
+                }
             }
 #undef SCREEN_STEP
-            if (colok) {
+            if (rows >= CSC_TILE_ROWS) {                             // (uniform) the 16 main row tiles are all inside
+#pragma unroll
+                for (int mi = 0; mi < 16; mi += 2)
+                    lmax = fmaxf(lmax, fmaxf(fmaxf(fmaxf(acc[mi][0], acc[mi][1]), fmaxf(acc[mi][2], acc[mi][3])),
+                                             fmaxf(fmaxf(acc[mi + 1][0], acc[mi + 1][1]), fmaxf(acc[mi + 1][2], acc[mi + 1][3]))));
+                if (REM) {
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        lmax = fmaxf(lmax, 256 + 4 * lq + rg < rows ? acc[MTW - 1][rg] : -INFINITY);
+                }
+            } else {
 #pragma unroll
                 for (int mi = 0; mi < MTW; ++mi)
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg)
-                        lmax = fmaxf(lmax, prow + 16 * mi + rg < rowlim ? acc[mi][rg] : -INFINITY);
+                        lmax = fmaxf(lmax, 16 * mi + 4 * lq + rg < rows ? acc[mi][rg] : -INFINITY);
             }
         }
-        lmax = wave_max(lmax);
-        if (lane == 63) atomicMax(&key[blk / NG + NG * (tile + ntile * rb)], fkey(lmax == lmax ? lmax : INFINITY));
+        lmax = wave_max(colok ? lmax : -INFINITY);
+        if (lane == 63) atomicMax(&key[p.blk / NG + NG * (p.tile + ntile * p.rb)], fkey(lmax == lmax ? lmax : INFINITY));
     }
     WAIT_VM(0);
 }
@@ -2711,12 +2736,16 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
         const _Float16* tlo = lo_all + (size_t)tile * nslab * SLABF;
         float lmax;
         if (with_rem) {
-            if (screen) gemm16x1_group<true>(th, g, tl->gs0[g], tl->gs1[g], rh, R16T_CS, rowbase, ring, acc, accr);
-            else gemm16x3_group<true>(th, tlo, g, tl->gs0[g], tl->gs1[g], rh, rl, R16T_CS, rowbase, ring, acc, accr);
+#ifdef CSC_SCREEN_CHECK
+            if (screen) gemm16x1_group<true>(th, g, tl->gs0[g], tl->gs1[g], rh, R16T_CS, rowbase, ring, acc, accr); else
+#endif
+            gemm16x3_group<true>(th, tlo, g, tl->gs0[g], tl->gs1[g], rh, rl, R16T_CS, rowbase, ring, acc, accr);
             lmax = group16x3_finish<true>(a, sl, tl, g, t, rowbase, permv, permr, acc, accr, lane_supp);
         } else {
-            if (screen) gemm16x1_group<false>(th, g, tl->gs0[g], tl->gs1[g], rh, R16T_CS, rowbase, ring, acc, accr);
-            else gemm16x3_group<false>(th, tlo, g, tl->gs0[g], tl->gs1[g], rh, rl, R16T_CS, rowbase, ring, acc, accr);
+#ifdef CSC_SCREEN_CHECK
+            if (screen) gemm16x1_group<false>(th, g, tl->gs0[g], tl->gs1[g], rh, R16T_CS, rowbase, ring, acc, accr); else
+#endif
+            gemm16x3_group<false>(th, tlo, g, tl->gs0[g], tl->gs1[g], rh, rl, R16T_CS, rowbase, ring, acc, accr);
             lmax = group16x3_finish<false>(a, sl, tl, g, t, rowbase, permv, permr, acc, accr, lane_supp);
         }
         return lmax;
