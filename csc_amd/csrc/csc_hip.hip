@@ -62,6 +62,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define T3_STAMP(i) do { const unsigned n_ = T3_CLK(); t3acc[i] += n_ - t3last; t3last = n_; } while (0)
 #define PROF_BUCKETS 256                // the counters are spread over buckets (block index) to keep the atomics apart
 __device__ unsigned long long g_prof[32][PROF_BUCKETS];
+// per-node trace of the chain kernel's product phase: {HW_ID, start, end (s_memtime, low 32 bits), block | XCC_ID << 24 | depth << 28}
+#define TRACE_CAP (1 << 18)
+__device__ unsigned g_trace[TRACE_CAP][4];
+__device__ unsigned g_trace_n;
 #define PROF_FIELDS unsigned long long prof_t; int prof_base;
 #define PROF_INIT(base) do { if (threadIdx.x == 0) { sl->prof_base = (base); sl->prof_t = __builtin_readcyclecounter(); } } while (0)
 #define PROF_MARK(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) { \
@@ -1740,6 +1744,9 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
         if (!(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 1e-30 && rnorm2 < 1e30)) { give_up(d); return; }
         build_r16(r64, N, (float)(1.0 / sqrt(rnorm2)), first, r16);
         __syncthreads();
+#ifdef CSC_PHASE_PROF
+        const unsigned trace_t0 = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
         // ---- sweep 1: group maxima -----------------------------------------------------------------------
         // widest atoms first, narrowest last: the last group stays in registers for sweep 2, and the narrow atoms'
         // group is both the one that most often holds the maximum (2 of 3 nodes on config 2) and the cheapest
@@ -1757,6 +1764,17 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
         for (int g = 0; g < NT / NG; ++g)
             gmax[g] = fmaxf(fmaxf(ll->wgmax[g][0], ll->wgmax[g][1]), fmaxf(ll->wgmax[g][2], ll->wgmax[g][3]));
         PROF_MARK(1);
+#ifdef CSC_PHASE_PROF
+        if (tid == 0) {
+            const unsigned at = atomicAdd(&g_trace_n, 1u);
+            if (at < TRACE_CAP) {
+                g_trace[at][0] = __builtin_amdgcn_s_getreg(63492);
+                g_trace[at][1] = trace_t0;
+                g_trace[at][2] = (unsigned)__builtin_amdgcn_s_memtime();
+                g_trace[at][3] = blockIdx.x | ((__builtin_amdgcn_s_getreg(6164) & 15u) << 24) | ((unsigned)d << 28);
+            }
+        }
+#endif
         const float m32 = fmaxf(fmaxf(gmax[0], gmax[1]), gmax[2]);
         const float tau = m32 - band;
         // ---- sweep 2: candidates from the groups that reach the band; the last group is still in registers --
@@ -3596,6 +3614,18 @@ int csc_prof_read(unsigned long long* out32, int reset) {
     }
     if (reset) { memset(host, 0, sizeof host); hipMemcpyToSymbol(HIP_SYMBOL(g_prof), host, sizeof host); }
     return 0;
+}
+// the chain kernel's trace since the last call: up to cap entries of 4 words -> out; returns the count
+int csc_prof_trace_read(unsigned* out, int cap) {
+    hipDeviceSynchronize();
+    unsigned n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_trace_n), sizeof n) != hipSuccess) return -1;
+    if (n > TRACE_CAP) n = TRACE_CAP;
+    if ((int)n > cap) n = (unsigned)cap;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), (size_t)n * 16) != hipSuccess) return -1;
+    const unsigned zero = 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), &zero, sizeof zero);
+    return (int)n;
 }
 #endif
 
