@@ -2681,6 +2681,72 @@ __device__ __forceinline__ float group16x3_finish(const LevelArgs& a, const Node
     return lmax;
 }
 
+// Where a node's screen bounds wait between screen16_kernel and mmp_level_tiled16_kernel: in the workspace row of
+// the node's FIRST child (child t of node j is j + t c^d >= F_d, so no other node's table lives in a row that a child
+// is written to), or, on the last level, which has no child rows, in the node's own row of the idle generation.
+__device__ __forceinline__ float* screen_table(const LevelArgs& a, size_t s, int j, int d) {
+    const size_t row = d + 1 < a.Kmax ? s * a.ts.F[d + 1] + j : s * a.ts.F[d] + j;
+    return reinterpret_cast<float*>(a.ws[(d + 1) & 1] + row * (size_t)a.NS);
+}
+
+// Stage 1 of the tiled fp16 path as a kernel of its own: it needs 14.5 KB + the ring of LDS and ~150 VGPRs, the
+// three-product stage 75 KB and 256, so apart the screen runs three workgroups per CU instead of two.  One workgroup per
+// node: residual -> ||r||, fp16 copies scaled to norm 64 (the same numbers mmp_level_tiled16_kernel builds), the
+// single-term maximum of every (row block, bank tile, column group) unit -> screen_table.
+__global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
+    extern __shared__ double lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = a.N, K = a.K, L = a.L, P = a.P, d = a.depth;
+    const int ntile = (K + CSC_TILE_COLS - 1) / CSC_TILE_COLS;
+    const int nslab = (L + SLAB - 1) / SLAB;
+    const int nrb_all = (P + CSC_TILE_ROWS - 1) / CSC_TILE_ROWS;
+    const bool rem = nrb_all > 1 && (P - (nrb_all - 1) * CSC_TILE_ROWS) <= 16;
+    const int nrb = rem ? nrb_all - 1 : nrb_all;
+    const int nunits = nrb * ntile * NG;
+    const int R16T_CS = r16t_stride(P, nslab * SLAB);
+    // LDS: red [4] doubles | rh [8][R16T_CS] halves | ring [TRING][TG_BLK] halves | key [nunits] | brange [9 ntile] shorts
+    double* red = lds_raw;
+    _Float16* rh = reinterpret_cast<_Float16*>(red + 4);
+    _Float16* ring = rh + R16_COPIES * R16T_CS;
+    unsigned* key = reinterpret_cast<unsigned*>(ring + TRING * TG_BLK);
+    unsigned short* brange = reinterpret_cast<unsigned short*>(key + nunits);
+    const int Fd = a.ts.F[d];
+    size_t s;
+    int j;
+    node_of_block(Fd, s, j);
+    const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
+    double v = 0.0;
+    for (int i = tid; i < N; i += WG) { const double x = rin[i]; v = fma(x, x, v); }
+    v = wave_sum(v);
+    if (lane == 63) red[wave] = v;
+    for (int u = tid; u < nunits; u += WG) key[u] = fkey(-INFINITY);
+    for (int e = tid; e < NT * ntile; e += WG) {                      // slab range of every 16-column block (s0 | s1 << 8)
+        const int32_t* mk = a.meta + (size_t)(e / NT) * META_INTS + CSC_TILE_COLS;
+        const int blk = e % NT;
+        int lo = nslab, hi = 0;
+        for (int q = 0; q < nslab; ++q)
+            if (((uint32_t)mk[q] >> blk) & 1u) { lo = min(lo, q); hi = q + 1; }
+        brange[e] = (unsigned short)(min(lo, hi) | (hi << 8));
+    }
+    __syncthreads();
+    const double rnorm2 = red[0] + red[1] + red[2] + red[3];
+    const float am2 = *a.amax2;
+    // the cases mmp_level_tiled16_kernel hands to fp32 without looking at the table
+    if (!(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 1e-30 && rnorm2 < 1e30)) return;
+    const double sc = 64.0 / sqrt(rnorm2);
+    for (int i = tid; i < R16_COPIES * R16T_CS; i += WG) {
+        const int c = i / R16T_CS, e = i - c * R16T_CS + c;
+        rh[i] = (_Float16)(e < N ? rin[e] * sc : 0.0);
+    }
+    __syncthreads();
+    const _Float16* hi_all = reinterpret_cast<const _Float16*>(a.bank16);
+    if (rem) screen_blocks16<true>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring);
+    else screen_blocks16<false>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring);
+    __syncthreads();
+    float* tab = screen_table(a, s, j, d);
+    for (int u = tid; u < nunits; u += WG) tab[u] = fkey_inv(key[u]);
+}
+
 __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArgs a) {
     extern __shared__ double lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2801,37 +2867,19 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
         // sweep can find there; the units in descending order of that bound
         const float e1 = (9.765625e-4f + 6.103515625e-05f + 1e-6f) * am + 2.98023223876953125e-08f * sqrtf((float)L) * (1.f + am);
         const float slack = (e1 + 0.5f * band) / unscale;
-        unsigned* key = reinterpret_cast<unsigned*>(tl->tmax0);
-        for (int u = tid; u < nunits; u += WG) key[u] = fkey(-INFINITY);
-        // slab range of every 16-column block of the bank (s0 | s1 << 8) -> tcur's space (NT * ntile <= 2048, checked at launch)
-        unsigned short* brange = reinterpret_cast<unsigned short*>(tl->tcur);
-        for (int e = tid; e < NT * ntile; e += WG) {
-            const int32_t* mk = a.meta + (size_t)(e / NT) * META_INTS + CSC_TILE_COLS;
-            const int blk = e % NT;
-            int lo = nslab, hi = 0;
-            for (int q = 0; q < nslab; ++q)
-                if (((uint32_t)mk[q] >> blk) & 1u) { lo = min(lo, q); hi = q + 1; }
-            brange[e] = (unsigned short)(min(lo, hi) | (hi << 8));
+        const float* tab = screen_table(a, s, j, d);                 // written by screen16_kernel, launched in front
+        for (int u = tid; u < nunits; u += WG) {
+            const float m = tab[u];
+            tl->tmax0[u] = m == m ? m + slack : INFINITY;            // (a NaN sorts first and is visited)
         }
-        __syncthreads();
-        if (rem) screen_blocks16<true>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring);
-        else screen_blocks16<false>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring);
-        __syncthreads();
-        if (tid == 0) tl->cur_tile = -1;
 #ifdef CSC_SCREEN_CHECK
         __syncthreads();
-        for (int u = 0; u < nunits; ++u) {
+        for (int u = 0; u < nunits; ++u) {                            // (equal up to the last bit of the two kernels' ||r||)
             const float m = unit_max(u, 0, true);
-            const float k = fkey_inv(key[u]);
-            if (tid == 0 && m != k && blockIdx.x < 64)
-                printf("block %d depth %d unit %d of %d: stream %g, unit %g\n", blockIdx.x, d, u, nunits, k, m);
+            if (tid == 0 && m != tab[u] && blockIdx.x < 64)
+                printf("block %d depth %d unit %d of %d: screen kernel %g, per-unit product %g\n", blockIdx.x, d, u, nunits, tab[u], m);
         }
-        __syncthreads();
 #endif
-        for (int u = tid; u < nunits; u += WG) {
-            const float m = fkey_inv(key[u]);
-            tl->tmax0[u] = m + slack;
-        }
         __syncthreads();
         for (int u = tid; u < nunits; u += WG) {
             const float v = tl->tmax0[u];
@@ -3392,11 +3440,19 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
     // buffer; its accumulation bound 3 L 2^-24 <= 2^-13 holds up to L = 682)
     const size_t lds16 = (size_t)ceil4(N) * 8 + 2 * (size_t)R16_COPIES * r16t_stride(P, Lp) * 2 + (size_t)TRING * TG_BLK * 2 +
                          sizeof(NodeLds) + sizeof(Tiled16Lds);
+    // its screen is a kernel of its own (three workgroups per CU); the bounds travel in a workspace row per node
+    const int nrb16 = (nrb > 1 && P - (nrb - 1) * CSC_TILE_ROWS <= 16) ? nrb - 1 : nrb;
+    const size_t units16 = (size_t)n_tiles(K) * nrb16 * NG;
+    const size_t lds_screen = 4 * 8 + (size_t)R16_COPIES * r16t_stride(P, Lp) * 2 + (size_t)TRING * TG_BLK * 2 + units16 * 4 +
+                              (((size_t)n_tiles(K) * NT * 2 + 15) & ~(size_t)15);
     const bool tiled16 = tiled && !(flags & CSC_FLAG_FP32_ONLY) && node_flags && mode == 0 && L <= 682 &&
-                         lds16 <= 80 * 1024 && (long long)n_tiles(K) * nrb * NG <= MAX_UNITS16 && n_tiles(K) * NT <= 2 * MAX_UNITS16;
+                         lds16 <= 80 * 1024 && (long long)n_tiles(K) * nrb * NG <= MAX_UNITS16 && n_tiles(K) * NT <= 2 * MAX_UNITS16 &&
+                         lds_screen <= 53 * 1024 && units16 * 4 <= (size_t)(N + TRI(max_sparsity) + max_sparsity) * 8;
     clear_stale_error();
-    if (tiled16) hipFuncSetAttribute((const void*)mmp_level_tiled16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds16);
+    if (tiled16) {
+        hipFuncSetAttribute((const void*)mmp_level_tiled16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+        hipFuncSetAttribute((const void*)screen16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_screen);
+    }
     hipFuncSetAttribute(tiled ? (const void*)mmp_level_tiled_kernel : (const void*)mmp_level_kernel,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (!tiled) hipFuncSetAttribute((const void*)mmp_level_followup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3433,6 +3489,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
             // the three-product fp16 filter takes the level; the fp32 kernel behind it redoes the flagged nodes
             a.flags = node_flags;
             a.bank16 = bank_tiles16s(d_bank32t, K, L, 0);
+            hipLaunchKernelGGL(screen16_kernel, dim3((unsigned)grid), dim3(WG), lds_screen, st, a);
             hipLaunchKernelGGL(mmp_level_tiled16_kernel, dim3((unsigned)grid), dim3(WG), lds16, st, a);
             a.bank16 = nullptr;
             hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);

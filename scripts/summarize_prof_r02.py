@@ -20,8 +20,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-LEVEL_KERNELS = ("mmp_level_lean_kernel", "mmp_level_followup_kernel", "mmp_level_kernel", "mmp_level_tiled16_kernel",
-                 "mmp_level_tiled_kernel", "reduce_kernel")
+LEVEL_KERNELS = ("mmp_level_lean_kernel", "mmp_level_followup_kernel", "mmp_level_kernel", "screen16_kernel",
+                 "mmp_level_tiled16_kernel", "mmp_level_tiled_kernel", "reduce_kernel")
 SIMDS = 1024
 
 
@@ -134,8 +134,8 @@ def per_kernel_totals(path, kernels):
 
 extra = {}
 for name, sub, groups, kernels in (
-        ("config3_l2", f"prof3l2_{tag}", ("pmc_fetch", "pmc_tcc", "pmc_tcp"), ("mmp_level_tiled16_kernel",)),
-        ("config3_instruction_mix", f"prof3sq_{tag}", ("pmc_a", "pmc_b"), ("mmp_level_tiled16_kernel",)),
+        ("config3_l2", f"prof3l2_{tag}", ("pmc_fetch", "pmc_tcc", "pmc_tcp"), ("screen16_kernel", "mmp_level_tiled16_kernel")),
+        ("config3_instruction_mix", f"prof3sq_{tag}", ("pmc_a", "pmc_b"), ("screen16_kernel", "mmp_level_tiled16_kernel")),
         ("config2_instruction_mix", f"prof2sq_{tag}", ("pmc_a", "pmc_b"), ("mmp_level_lean_kernel", "mmp_level_kernel"))):
     d = {}
     for g in groups:
