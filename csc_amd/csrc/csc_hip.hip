@@ -2198,12 +2198,12 @@ static __host__ __device__ inline int r16t_stride(int P, int Lp) {
 #define MAX_UNITS16 1024               // (row block, bank tile, column group) units per node, and at most 2048 16-column
                                        // blocks in the bank: K up to 32 768 at P <= 272
 struct Tiled16Lds {
-    float tmax0[MAX_UNITS16];      // unsuppressed unit maxima (first sibling's sweep)
-    float tcur[MAX_UNITS16];       // unit maxima of the current sibling's sweep (-inf = skipped)
+    float tmax0[MAX_UNITS16];      // upper bound of each unit's three-product entries (screen maximum + eps1 + eps3)
     int sib_pos[CSC_MAX_CONNECTIONS], sib_atom[CSC_MAX_CONNECTIONS];
     int gs0[NG], gs1[NG];          // slab range of each column group of the current tile
     int cur_tile;                  // bank tile whose metadata sl->perm / sl->masks / gs0 / gs1 hold (-1 = none)
-    short order[MAX_UNITS16];      // units by descending unsuppressed maximum (the later siblings' sweep order)
+    short order[MAX_UNITS16];      // units by descending bound (the sweep order of every sibling)
+    float cand_v[CAND_CAP];        // three-product values of the candidates taken during the sweep
 };
 
 // group-slab s of group g -> one ring slot: 6 KiB = 3 hi blocks + 3 lo blocks; every wave issues two copies (one
@@ -2850,16 +2850,57 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
         if (tid == 0) tl->cur_tile = tile;
         __syncthreads();
     };
-    // the maximum of a unit over the workgroup (suppressed entries count as 0)
+    // the maximum of a unit over the workgroup (suppressed entries count as 0); its entries stay in acc / accr
+    int unit_rowbase = 0;
     auto unit_max = [&](int u, int t, bool screen) -> float {
         tile_setup((u / NG) % ntile);
         bool lane_supp;
-        int rowbase;
-        const float lmax = unit(u, t, screen, lane_supp, rowbase);
+        const float lmax = unit(u, t, screen, lane_supp, unit_rowbase);
         const float bv = wave_max(lane_supp ? fmaxf(lmax, 0.f) : lmax);
         if (lane == 63) sl->wmax[wave] = bv;
         __syncthreads();
         return fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
+    };
+    // the entries of the unit in acc / accr that reach tauv -> candidate list (flattened index, value)
+    auto collect = [&](int u, float tauv) {
+        const int g = u % NG, rowbase = unit_rowbase;
+        const int rowK = (rowbase + 64 * wave + 4 * lq) * K;
+        uint32_t mk[2] = {0u, 0u};
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                for (int nj = 0; nj < NG; ++nj) {
+                    const int e = (4 * mi + rg) * NG + nj;
+                    mk[e >> 5] |= (acc[mi][nj][rg] >= tauv) ? (1u << (e & 31)) : 0u;
+                }
+        if (mk[0] | mk[1]) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                    for (int nj = 0; nj < NG; ++nj) {
+                        const int e = (4 * mi + rg) * NG + nj;
+                        if ((mk[e >> 5] >> (e & 31)) & 1u) {
+                            const int slot = atomicAdd(&sl->cand_cnt, 1);
+                            if (slot < CAND_CAP) {
+                                sl->cand_idx[slot] = rowK + (16 * mi + rg) * K + sl->perm[16 * (NG * g + nj) + lr];
+                                tl->cand_v[slot] = acc[mi][nj][rg];
+                            }
+                        }
+                    }
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+            if (accr[rg] >= tauv) {
+                const int slot = atomicAdd(&sl->cand_cnt, 1);
+                if (slot < CAND_CAP) {
+                    sl->cand_idx[slot] = (rowbase + CSC_TILE_ROWS + 4 * lq + rg) * K + permr;
+                    tl->cand_v[slot] = accr[rg];
+                }
+            }
     };
     const float bandu = band / unscale;                              // the band in accumulator units
     {
@@ -2894,81 +2935,59 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
     }
 
     for (int t = 0; t < nch; ++t) {
-        // ---- sweep 1: three-product maxima of the units that can reach the band of the running maximum: by descending
-        // bound, the first few hold the maximum, and once a unit cannot reach the band no later one can
+        // ---- the three-product sweep over the units that can reach the band of the running maximum: by descending
+        // bound, the first few hold the maximum, and once a unit cannot reach the band no later one can.  Candidates are
+        // taken on the way, against the RUNNING maximum: it only rises, so the list is a superset of the entries within
+        // the band of the final one and is cut down to them below -- no unit is multiplied twice
         float gmax = -INFINITY;                                       // workgroup-uniform
-        for (int u = tid; u < nunits; u += WG) tl->tcur[u] = -INFINITY;
+        int visited = 0;
+        if (tid == 0) sl->cand_cnt = 0;
         __syncthreads();
-        for (int i = 0; i < nunits; ++i) {
+        for (int i = 0; i < nunits; ++i, ++visited) {
             const int u = tl->order[i];
             if ((t > 0 ? fmaxf(tl->tmax0[u], 0.f) : tl->tmax0[u]) < gmax - bandu) break;       // (uniform)
 #ifdef CSC_PHASE_PROF
             if (tid == 0) atomicAdd(&g_prof[5][blockIdx.x % PROF_BUCKETS], 1ull);
 #endif
             const float m = unit_max(u, t, false);
-            if (tid == 0) tl->tcur[u] = m;
             gmax = fmaxf(gmax, m);
+            if (m > -INFINITY && m >= gmax - bandu) collect(u, gmax - bandu);
         }
         __syncthreads();
         PROF_MARK(2);
-        // ---- sweep 2: candidates from the units that reach the band --------------------------------------
         const float tau = gmax - bandu;
         // the value 0 of suppressed entries inside the band, or no finite maximum: the fp32 kernel decides
         if ((0.f >= tau && t > 0) || !(gmax > -INFINITY) || !(gmax < INFINITY)) {
             if (tid == 0) { *flag = 1; if (a.stats) atomicAdd(&a.stats[3], 1); }
             return;
         }
-        if (tid == 0) sl->cand_cnt = 0;
-        __syncthreads();
-        for (int u = 0; u < nunits; ++u) {
-            if (!(tl->tcur[u] >= tau)) continue;                      // uniform
-            const int g = u % NG;
-#ifdef CSC_PHASE_PROF
-            if (tid == 0) atomicAdd(&g_prof[6][blockIdx.x % PROF_BUCKETS], 1ull);
-#endif
-            tile_setup((u / NG) % ntile);
-            bool lane_supp;
-            int rowbase;
-            const float lmax = unit(u, t, false, lane_supp, rowbase);
-            if (lmax >= tau) {
-                const int rowK = (rowbase + 64 * wave + 4 * lq) * K;
-                uint32_t mk[2] = {0u, 0u};
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-                        for (int nj = 0; nj < NG; ++nj) {
-                            const int e = (4 * mi + rg) * NG + nj;
-                            mk[e >> 5] |= (acc[mi][nj][rg] >= tau) ? (1u << (e & 31)) : 0u;
-                        }
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    uint32_t mm = mk[w];
-                    while (mm) {
-                        const int e = 32 * w + __builtin_ctz(mm);
-                        mm &= mm - 1;
-                        const int r = e / NG, nj = e - r * NG;
-                        const int idx = rowK + (16 * (r >> 2) + (r & 3)) * K + sl->perm[16 * (NG * g + nj) + lr];
-                        const int slot = atomicAdd(&sl->cand_cnt, 1);
-                        if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
-                    }
-                }
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg)
-                    if (accr[rg] >= tau) {
-                        const int idx = (rowbase + CSC_TILE_ROWS + 4 * lq + rg) * K + permr;
-                        const int slot = atomicAdd(&sl->cand_cnt, 1);
-                        if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
-                    }
+        if (sl->cand_cnt > CAND_CAP) {
+            // the list overflowed, perhaps only with entries above an early, lower threshold: once more over the visited
+            // units with the final one (rare); more than CAND_CAP entries in the band itself: fp32
+            __syncthreads();
+            if (tid == 0) sl->cand_cnt = 0;
+            for (int i = 0; i < visited; ++i) {
+                const int u = tl->order[i];
+                const float m = unit_max(u, t, false);
+                if (m >= tau) collect(u, tau);
             }
+            __syncthreads();
+            if (sl->cand_cnt > CAND_CAP) {
+                if (tid == 0) { *flag = 1; if (a.stats) atomicAdd(&a.stats[3], 1); }
+                return;
+            }
+        }
+        // keep the entries within the band of the final maximum (in place; cand_cnt <= 128: one thread)
+        __syncthreads();
+        if (tid == 0) {
+            const int n = sl->cand_cnt;
+            int k = 0;
+            for (int q = 0; q < n; ++q)
+                if (tl->cand_v[q] >= tau) sl->cand_idx[k++] = sl->cand_idx[q];
+            sl->cand_cnt = k;
         }
         __syncthreads();
         const int ncand_raw = sl->cand_cnt;
-        if (ncand_raw > CAND_CAP) {                                   // too many entries in the band: fp32
-            if (tid == 0) { *flag = 1; if (a.stats) atomicAdd(&a.stats[3], 1); }
-            return;
-        }
         PROF_MARK(3);
         rescore_and_choose(a, sl, r64, ncand_raw, false, d);
         const int jc = j + t * stride;
