@@ -2200,8 +2200,8 @@ static __host__ __device__ inline int r16t_stride(int P, int Lp) {
 struct Tiled16Lds {
     float tmax0[MAX_UNITS16];      // upper bound of each unit's three-product entries (screen maximum + eps1 + eps3)
     int sib_pos[CSC_MAX_CONNECTIONS], sib_atom[CSC_MAX_CONNECTIONS];
-    int gs0[NG], gs1[NG];          // slab range of each column group of the current tile
-    int cur_tile;                  // bank tile whose metadata sl->perm / sl->masks / gs0 / gs1 hold (-1 = none)
+    unsigned short urange[MAX_UNITS16];   // slab range s0 | s1 << 8 of column group g of bank tile: [g + NG tile]
+    int permbuf[2][CSC_TILE_COLS]; // atom of each column of the current / the next unit's bank tile (begin_unit16x3)
     short order[MAX_UNITS16];      // units by descending bound (the sweep order of every sibling)
     float cand_v[CAND_CAP];        // three-product values of the candidates taken during the sweep
 };
@@ -2216,6 +2216,30 @@ __device__ __forceinline__ void stage_group16x3(const _Float16* hi_slab, const _
     if (lane < 32)
         __builtin_amdgcn_global_load_lds((gptr_t)(lo_slab + (NG * g + p - NG) * BLKF + half + lane * 8),
                                          (lptr_t)(lslot + p * BLKF + half), 16, 0, 0);
+}
+
+// What a unit needs before its product can start, issued as early as possible -- for the sweep's NEXT unit right
+// behind the current unit's last slab, so that the L2 / MALL latency (the units of a node are a scattered handful of
+// a 20 MB bank: 70 % L2 misses) runs under the current unit's epilogue: the column -> atom map of the unit's bank tile
+// -> permbuf[buf] (LDS-DMA, 48 ints per wave on waves 0..2; issued BEFORE the ring copies, so the product's vmcnt
+// waits cover it), and the group's first three slabs -> ring slots 0..2.  The ring must be idle (behind the barrier
+// that ends gemm16x3_group).
+__device__ __forceinline__ void begin_unit16x3(const LevelArgs& a, const _Float16* hi_all, const _Float16* lo_all,
+                                               Tiled16Lds* tl, int u, int buf, int ntile, int nslab, _Float16* ring) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = u % NG, tile = (u / NG) % ntile;
+    if (wave < 3 && lane < 48)
+        __builtin_amdgcn_global_load_lds((gptr_t)(a.meta + (size_t)tile * META_INTS + wave * 48 + lane),
+                                         (lptr_t)(&tl->permbuf[buf][wave * 48]), 4, 0, 0);
+    const int pk = __builtin_amdgcn_readfirstlane((int)tl->urange[g + NG * tile]);
+    const int s0 = pk & 0xff, s1 = pk >> 8;
+    const _Float16* hi = hi_all + (size_t)tile * nslab * SLABF;
+    const _Float16* lo = lo_all + (size_t)tile * nslab * SLABF;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (s0 + q < s1)
+            stage_group16x3(hi + (size_t)(s0 + q) * SLABF, lo + (size_t)(s0 + q) * SLABF, ring + q * TG_BLK, g, wave, lane);
 }
 
 // acc[mi][nj]: positions rowbase + 64 wave + 16 mi + ..., column tile 3 g + nj, over slabs [s0, s1) of the tile at
@@ -2236,11 +2260,8 @@ __device__ __forceinline__ void gemm16x3_group(const _Float16* __restrict__ hi, 
     // 64 wave + 16 mi + lr, i.e. one aligned 16-byte read of shifted copy row mod 8
     const int aoff = (lr & 7) * R16T_CS + rowbase + 64 * wave + (lr & 8) + 8 * lq;
     const int roff = (lr & 7) * R16T_CS + rowbase + CSC_TILE_ROWS + (lr & 8) + 8 * lq;
-    WAIT_VM(0);                                                      // nothing of ours in flight: the counts below hold
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-        if (s0 + q < s1)
-            stage_group16x3(hi + (size_t)(s0 + q) * SLABF, lo + (size_t)(s0 + q) * SLABF, ring + q * TG_BLK, g, wave, lane);
+    // the copies of the group's first three slabs (slots 0..2) are in flight already: begin_unit16x3 issued them, as
+    // this wave's most recent ring copies (vector loads issued since only make the waits below stricter)
     f16x8 ah[2][MT], al[2][MT], arh[2], arl[2], bh[2][NG], bl[2][NG];
 #ifdef CSC_PHASE_PROF
     unsigned t3acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t3last = T3_CLK();
@@ -2599,7 +2620,7 @@ __device__ __forceinline__ void screen_blocks16(const LevelArgs& a, const _Float
 // returns the lane's maximum over its unsuppressed entries (remainder tile included), lane_supp = it holds a
 // suppressed one
 template <bool REM>
-__device__ __forceinline__ float group16x3_finish(const LevelArgs& a, const NodeLds* sl, const Tiled16Lds* tl, int g, int t,
+__device__ __forceinline__ float group16x3_finish(const LevelArgs& a, const int* perm, const Tiled16Lds* tl, int g, int t,
                                                   int rowbase, int (&permv)[NG], int& permr, f32x4 (&acc)[MT][NG],
                                                   f32x4& accr, bool& lane_supp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2608,8 +2629,8 @@ __device__ __forceinline__ float group16x3_finish(const LevelArgs& a, const Node
     const int prow = rowbase + 64 * wave + 4 * lq;
     const int rrow = rowbase + CSC_TILE_ROWS + 4 * lq;
 #pragma unroll
-    for (int nj = 0; nj < NG; ++nj) permv[nj] = sl->perm[16 * (NG * g + nj) + lr];
-    permr = wave < NG ? sl->perm[16 * (NG * g + wave) + lr] : -1;
+    for (int nj = 0; nj < NG; ++nj) permv[nj] = perm[16 * (NG * g + nj) + lr];
+    permr = wave < NG ? perm[16 * (NG * g + wave) + lr] : -1;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
         if (rowbase + 64 * wave + 16 * mi + 15 >= P) {               // wave-uniform
@@ -2811,55 +2832,81 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
 
     f32x4 acc[MT][NG], accr;
     int permv[NG], permr;
-    // one unit: GEMM + masks + suppression; the unscaled lane maximum
-    auto unit = [&](int u, int t, bool screen, bool& lane_supp, int& rowbase) -> float {
+    // slab range of every (bank tile, column group): outside it the group's blocks are zero padding
+    for (int e = tid; e < NG * ntile; e += WG) {
+        const int32_t* mk = a.meta + (size_t)(e / NG) * META_INTS + CSC_TILE_COLS;
+        const int g = e % NG;
+        int lo = nslab, hi = 0;
+        for (int q = 0; q < nslab; ++q)
+            if (((uint32_t)mk[q] >> (NG * g)) & 7u) { lo = min(lo, q); hi = q + 1; }
+        tl->urange[e] = (unsigned short)(min(lo, hi) | (hi << 8));
+    }
+    __syncthreads();
+    // One unit: product + masks + suppression -> the unscaled lane maximum; the entries stay in acc / accr.
+    // begin_unit16x3(u, buf) has been issued (by the unit before, or by the caller); `next` >= 0: the unit the sweep is
+    // likely to take next, begun into the other buffer as soon as the ring is idle.
+    int unit_rowbase = 0;
+    const int* unit_perm = tl->permbuf[0];
+#ifdef CSC_PHASE_PROF
+    // unit-level clocks (thread 0): slots 0 product, 1 begin-next + masks, 2 maximum + barriers, 3 candidates + loop
+    unsigned long long unit_t = __builtin_readcyclecounter();
+#define UNIT_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (tid == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); \
+        atomicAdd(&g_prof[i][blockIdx.x % PROF_BUCKETS], n_ - unit_t); unit_t = n_; } } while (0)
+#else
+#define UNIT_STAMP(i)
+#endif
+    auto unit = [&](int u, int t, bool screen, int buf, int next, bool& lane_supp) -> float {
         const int g = u % NG, tile = (u / NG) % ntile, rb = u / (NG * ntile);
         const bool with_rem = rem && rb == nrb - 1;                  // uniform
-        rowbase = rb * CSC_TILE_ROWS;
+        const int rowbase = rb * CSC_TILE_ROWS;
+        const int pk = tl->urange[g + NG * tile];
+        const int s0 = pk & 0xff, s1 = pk >> 8;
         const _Float16* th = hi_all + (size_t)tile * nslab * SLABF;
         const _Float16* tlo = lo_all + (size_t)tile * nslab * SLABF;
+        unit_rowbase = rowbase;
+        unit_perm = tl->permbuf[buf];
+        if (s0 >= s1) {                                              // nothing was staged: the map has to land by itself
+            WAIT_VM(0);
+            __syncthreads();
+        }
         float lmax;
+        UNIT_STAMP(3);
         if (with_rem) {
 #ifdef CSC_SCREEN_CHECK
-            if (screen) gemm16x1_group<true>(th, g, tl->gs0[g], tl->gs1[g], rh, R16T_CS, rowbase, ring, acc, accr); else
+            if (screen) gemm16x1_group<true>(th, g, s0, s1, rh, R16T_CS, rowbase, ring, acc, accr); else
 #endif
-            gemm16x3_group<true>(th, tlo, g, tl->gs0[g], tl->gs1[g], rh, rl, R16T_CS, rowbase, ring, acc, accr);
-            lmax = group16x3_finish<true>(a, sl, tl, g, t, rowbase, permv, permr, acc, accr, lane_supp);
+            gemm16x3_group<true>(th, tlo, g, s0, s1, rh, rl, R16T_CS, rowbase, ring, acc, accr);
+            UNIT_STAMP(0);
+            if (next >= 0) begin_unit16x3(a, hi_all, lo_all, tl, next, buf ^ 1, ntile, nslab, ring);
+            lmax = group16x3_finish<true>(a, unit_perm, tl, g, t, rowbase, permv, permr, acc, accr, lane_supp);
         } else {
 #ifdef CSC_SCREEN_CHECK
-            if (screen) gemm16x1_group<false>(th, g, tl->gs0[g], tl->gs1[g], rh, R16T_CS, rowbase, ring, acc, accr); else
+            if (screen) gemm16x1_group<false>(th, g, s0, s1, rh, R16T_CS, rowbase, ring, acc, accr); else
 #endif
-            gemm16x3_group<false>(th, tlo, g, tl->gs0[g], tl->gs1[g], rh, rl, R16T_CS, rowbase, ring, acc, accr);
-            lmax = group16x3_finish<false>(a, sl, tl, g, t, rowbase, permv, permr, acc, accr, lane_supp);
+            gemm16x3_group<false>(th, tlo, g, s0, s1, rh, rl, R16T_CS, rowbase, ring, acc, accr);
+            UNIT_STAMP(0);
+            if (next >= 0) begin_unit16x3(a, hi_all, lo_all, tl, next, buf ^ 1, ntile, nslab, ring);
+            lmax = group16x3_finish<false>(a, unit_perm, tl, g, t, rowbase, permv, permr, acc, accr, lane_supp);
         }
+        UNIT_STAMP(1);
         return lmax;
     };
-    // per bank tile: metadata -> LDS, slab range of each column group (outside it the group's blocks are zero padding)
-    if (tid == 0) tl->cur_tile = -1;
-    auto tile_setup = [&](int tile) {
-        __syncthreads();                                              // everybody is done with the tile before
-        if (tl->cur_tile == tile) return;                             // uniform
-        load_tile_meta(a, sl, tile);
-        if (tid < NG) {
-            int lo = nslab, hi = 0;
-            for (int q = 0; q < nslab; ++q)
-                if ((sl->masks[q] >> (NG * tid)) & 7u) { lo = min(lo, q); hi = q + 1; }
-            tl->gs0[tid] = min(lo, hi);
-            tl->gs1[tid] = hi;
-        }
-        if (tid == 0) tl->cur_tile = tile;
-        __syncthreads();
-    };
-    // the maximum of a unit over the workgroup (suppressed entries count as 0); its entries stay in acc / accr
-    int unit_rowbase = 0;
-    auto unit_max = [&](int u, int t, bool screen) -> float {
-        tile_setup((u / NG) % ntile);
+    // the maximum of a unit over the workgroup (suppressed entries count as 0)
+    auto unit_max = [&](int u, int t, bool screen, int buf, int next) -> float {
         bool lane_supp;
-        const float lmax = unit(u, t, screen, lane_supp, unit_rowbase);
+        const float lmax = unit(u, t, screen, buf, next, lane_supp);
         const float bv = wave_max(lane_supp ? fmaxf(lmax, 0.f) : lmax);
+        __syncthreads();                                              // (the maxima of the unit before have been read)
         if (lane == 63) sl->wmax[wave] = bv;
         __syncthreads();
+        UNIT_STAMP(2);
         return fmaxf(fmaxf(sl->wmax[0], sl->wmax[1]), fmaxf(sl->wmax[2], sl->wmax[3]));
+    };
+    // a unit on its own (no unit before it to begin it)
+    auto unit_max_cold = [&](int u, int t, bool screen) -> float {
+        __syncthreads();                                              // the ring and permbuf[0] are idle
+        begin_unit16x3(a, hi_all, lo_all, tl, u, 0, ntile, nslab, ring);
+        return unit_max(u, t, screen, 0, -1);
     };
     // the entries of the unit in acc / accr that reach tauv -> candidate list (flattened index, value)
     auto collect = [&](int u, float tauv) {
@@ -2886,7 +2933,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
                         if ((mk[e >> 5] >> (e & 31)) & 1u) {
                             const int slot = atomicAdd(&sl->cand_cnt, 1);
                             if (slot < CAND_CAP) {
-                                sl->cand_idx[slot] = rowK + (16 * mi + rg) * K + sl->perm[16 * (NG * g + nj) + lr];
+                                sl->cand_idx[slot] = rowK + (16 * mi + rg) * K + unit_perm[16 * (NG * g + nj) + lr];
                                 tl->cand_v[slot] = acc[mi][nj][rg];
                             }
                         }
@@ -2916,7 +2963,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
 #ifdef CSC_SCREEN_CHECK
         __syncthreads();
         for (int u = 0; u < nunits; ++u) {                            // (equal up to the last bit of the two kernels' ||r||)
-            const float m = unit_max(u, 0, true);
+            const float m = unit_max_cold(u, 0, true);
             if (tid == 0 && m != tab[u] && blockIdx.x < 64)
                 printf("block %d depth %d unit %d of %d: screen kernel %g, per-unit product %g\n", blockIdx.x, d, u, nunits, tab[u], m);
         }
@@ -2943,16 +2990,18 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
         int visited = 0;
         if (tid == 0) sl->cand_cnt = 0;
         __syncthreads();
+        begin_unit16x3(a, hi_all, lo_all, tl, tl->order[0], 0, ntile, nslab, ring);
         for (int i = 0; i < nunits; ++i, ++visited) {
             const int u = tl->order[i];
             if ((t > 0 ? fmaxf(tl->tmax0[u], 0.f) : tl->tmax0[u]) < gmax - bandu) break;       // (uniform)
 #ifdef CSC_PHASE_PROF
             if (tid == 0) atomicAdd(&g_prof[5][blockIdx.x % PROF_BUCKETS], 1ull);
 #endif
-            const float m = unit_max(u, t, false);
+            const float m = unit_max(u, t, false, i & 1, i + 1 < nunits ? (int)tl->order[i + 1] : -1);
             gmax = fmaxf(gmax, m);
             if (m > -INFINITY && m >= gmax - bandu) collect(u, gmax - bandu);
         }
+        WAIT_VM(0);                                                   // the copies begun for a unit the sweep did not take
         __syncthreads();
         PROF_MARK(2);
         const float tau = gmax - bandu;
@@ -2968,7 +3017,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
             if (tid == 0) sl->cand_cnt = 0;
             for (int i = 0; i < visited; ++i) {
                 const int u = tl->order[i];
-                const float m = unit_max(u, t, false);
+                const float m = unit_max_cold(u, t, false);
                 if (m >= tau) collect(u, tau);
             }
             __syncthreads();

@@ -36,3 +36,10 @@ print(f"phases, clocks per node (thread 0): total {tot2 / nodes:.0f}")
 for nme, x in zip(names2, v[16:26]):
     print(f"  {nme:36s} {x / nodes:10.0f}  {100 * x / tot2:5.1f} %")
 
+
+units = v[5] + v[6]
+if units:
+    print(f"three-product units: {units / nodes:.1f} per node, clocks per unit (thread 0):")
+    for nme, x in zip(["product (first wait included)", "begin the next unit + masks / suppression", "maximum + barriers",
+                       "candidates + between units"], v[0:4]):
+        print(f"  {nme:44s} {x / units:8.0f}")
