@@ -215,3 +215,21 @@ def test_three_product_filter_equals_fp32_path(large_dic):
         assert got.stats[3] <= 0.05 * n_nodes, (got.stats, n_nodes)
         for name in ("node_pos", "node_atom", "node_mse", "node_coef", "rec_mse", "rec_leaf", "rec_sel"):
             assert np.array_equal(getattr(got, name), getattr(ref, name)), (name, len(bank.bank64))
+
+
+def test_tiled_fp16_front_equals_fp32_on_random_dictionaries():
+    """Random dictionaries beyond one register tile (224 ... 1200 atoms; 40 ... 600 positions: one row block with and
+    without the 16-row remainder tile, several row blocks -- where the fp16 front does not fit its LDS and the fp32 kernel
+    takes every node --, partly filled last bank tiles; 1 ... 4 children per node; noisy, noiseless, near-tie and huge
+    signals): the default path (screen + three-product fp16 kernels in front of the fp32 tiled kernel) and the fp32-only
+    path give the same trees (scripts/fuzz_tiled.py)."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        import fuzz_tiled
+        assert fuzz_tiled.run(14, 7, verbose=False) == 0
+    finally:
+        os.chdir(cwd)
