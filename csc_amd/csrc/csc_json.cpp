@@ -185,8 +185,6 @@ int csc_sparvar_json_write(const char* path, int append, const void* records, in
     F.K = K; F.connections = connections; F.n_atoms = n_atoms;
     F.records = static_cast<const char*>(records); F.ids = ids; F.snr = snr; F.snr_is_int = snr_is_int;
     F.rec_bytes = (size_t)K * (16 + 8 * (size_t)K);
-    // worst case of one signal entry: K results x (K atoms x (~60 + tail) + ~200)
-    F.max_bytes = 512 + (size_t)K * (256 + 24 * (size_t)K + (size_t)K * (96 + 3 * 32 + 8 * 4 * 7));
     // one pre-formatted tail per atom: ,\n"b": ..,\n"y": ..,\n"s": ..\n}   (everything after the "x" line)
     F.atom_tail.resize((size_t)n_atoms);
     char num[48];
@@ -211,6 +209,14 @@ int csc_sparvar_json_write(const char* path, int append, const void* records, in
     F.atoms_key = "\",\n" + i4 + "\"atoms\": [\n";
     F.open_atom = i5 + "{\n" + i6 + "\"x\": ";
     F.close_sig = "\n" + i2 + "]\n" + i1 + "}";
+    // worst case of one signal entry, from the pieces themselves (an integer takes <= 21 characters, a float <= 25)
+    size_t tail_max = 0;
+    for (const std::string& t : F.atom_tail) tail_max = std::max(tail_max, t.size());
+    const size_t atom_max = 2 + F.open_atom.size() + 21 + tail_max;
+    const size_t result_max = F.open_res.size() + 25 + F.path_key.size() + 22 * (size_t)K + F.atoms_key.size() +
+                              (size_t)K * atom_max + F.delay_line.size() + 2;
+    F.max_bytes = F.open_sig.size() + 21 + F.snr_key.size() + 25 + F.results_key.size() + (size_t)K * result_max +
+                  F.close_sig.size() + 2 + 64;
 
     bool ok = true;
     int64_t bad_record = -1;
