@@ -2752,8 +2752,9 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
     __syncthreads();
     const double rnorm2 = red[0] + red[1] + red[2] + red[3];
     const float am2 = *a.amax2;
-    // the cases mmp_level_tiled16_kernel hands to fp32 without looking at the table
-    if (!(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 1e-30 && rnorm2 < 1e30)) return;
+    // the cases mmp_level_tiled16_kernel hands to fp32 without looking at the table (its ||r||^2 is summed in another
+    // order: the window here is a little wider, so that a node it takes always finds its table written)
+    if (!(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 0.5e-30 && rnorm2 < 2e30)) return;
     const double sc = 64.0 / sqrt(rnorm2);
     for (int i = tid; i < R16_COPIES * R16T_CS; i += WG) {
         const int c = i / R16T_CS, e = i - c * R16T_CS + c;
