@@ -3506,7 +3506,9 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
     if (lds > 150 * 1024) FAIL(-8, "signal too long for the LDS-resident node kernel (%zu B)", lds);
     if (!tiled && (size_t)K * (W + 1) * 4 > 2 * SLABF * 4) FAIL(-8, "similarity row does not fit the slab buffer");
     // dictionaries beyond one register tile: the fp16 three-product filter in front of the fp32 kernel (needs the flag
-    // buffer; its accumulation bound 3 L 2^-24 <= 2^-13 holds up to L = 682)
+    // buffer; its accumulation bound 3 L 2^-24 <= 2^-13 holds up to L = 682).  One row block (P <= 272) takes 75 KB of
+    // LDS: two workgroups per CU; the window copies of a second and third row block bring it to 85 - 95 KB and one
+    // workgroup per CU, which is still 5 - 6x the fp32 kernel
     const size_t lds16 = (size_t)ceil4(N) * 8 + 2 * (size_t)R16_COPIES * r16t_stride(P, Lp) * 2 + (size_t)TRING * TG_BLK * 2 +
                          sizeof(NodeLds) + sizeof(Tiled16Lds);
     // its screen is a kernel of its own (three workgroups per CU); the bounds travel in a workspace row per node
@@ -3515,8 +3517,8 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
     const size_t lds_screen = 4 * 8 + (size_t)R16_COPIES * r16t_stride(P, Lp) * 2 + (size_t)TRING * TG_BLK * 2 + units16 * 4 +
                               (((size_t)n_tiles(K) * NT * 2 + 15) & ~(size_t)15);
     const bool tiled16 = tiled && !(flags & CSC_FLAG_FP32_ONLY) && node_flags && mode == 0 && L <= 682 &&
-                         lds16 <= 80 * 1024 && (long long)n_tiles(K) * nrb * NG <= MAX_UNITS16 && n_tiles(K) * NT <= 2 * MAX_UNITS16 &&
-                         lds_screen <= 53 * 1024 && units16 * 4 <= (size_t)(N + TRI(max_sparsity) + max_sparsity) * 8;
+                         lds16 <= 150 * 1024 && (long long)n_tiles(K) * nrb * NG <= MAX_UNITS16 && n_tiles(K) * NT <= 2 * MAX_UNITS16 &&
+                         lds_screen <= 100 * 1024 && units16 * 4 <= (size_t)(N + TRI(max_sparsity) + max_sparsity) * 8;
     clear_stale_error();
     if (tiled16) {
         hipFuncSetAttribute((const void*)mmp_level_tiled16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);

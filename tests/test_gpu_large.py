@@ -219,8 +219,7 @@ def test_three_product_filter_equals_fp32_path(large_dic):
 
 def test_tiled_fp16_front_equals_fp32_on_random_dictionaries():
     """Random dictionaries beyond one register tile (224 ... 1200 atoms; 40 ... 600 positions: one row block with and
-    without the 16-row remainder tile, several row blocks -- where the fp16 front does not fit its LDS and the fp32 kernel
-    takes every node --, partly filled last bank tiles; 1 ... 4 children per node; noisy, noiseless, near-tie and huge
+    without the 16-row remainder tile, two and three row blocks (one workgroup per CU), partly filled last bank tiles; 1 ... 4 children per node; noisy, noiseless, near-tie and huge
     signals): the default path (screen + three-product fp16 kernels in front of the fp32 tiled kernel) and the fp32-only
     path give the same trees (scripts/fuzz_tiled.py)."""
     import sys
