@@ -2195,6 +2195,7 @@ static __host__ __device__ inline int r16t_stride(int P, int Lp) {
 #define TG_BLK (2 * NG * BLKF)         // halves of one group-slab: 3 hi blocks, 3 lo blocks
 #define EPS3_ACC 1.220703125e-04f      // 2^-13
 
+#define CAND_CAP16 (2 * CAND_CAP)
 #define MAX_UNITS16 1024               // (row block, bank tile, column group) units per node, and at most 2048 16-column
                                        // blocks in the bank: K up to 32 768 at P <= 272
 struct Tiled16Lds {
@@ -2203,7 +2204,11 @@ struct Tiled16Lds {
     unsigned short urange[MAX_UNITS16];   // slab range s0 | s1 << 8 of column group g of bank tile: [g + NG tile]
     int permbuf[2][CSC_TILE_COLS]; // atom of each column of the current / the next unit's bank tile (begin_unit16x3)
     short order[MAX_UNITS16];      // units by descending bound (the sweep order of every sibling)
-    float cand_v[CAND_CAP];        // three-product values of the candidates taken during the sweep
+    // candidates taken during the sweep: flattened index and three-product value.  Twice the capacity of the shared
+    // re-score (a flat residual at the last level puts 130 - 200 entries of a finely sampled dictionary in the band);
+    // the re-score then runs over the list in two halves
+    int cand_i[CAND_CAP16];
+    float cand_v[CAND_CAP16];
 };
 
 // group-slab s of group g -> one ring slot: 6 KiB = 3 hi blocks + 3 lo blocks; every wave issues two copies (one
@@ -2933,8 +2938,8 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
                         const int e = (4 * mi + rg) * NG + nj;
                         if ((mk[e >> 5] >> (e & 31)) & 1u) {
                             const int slot = atomicAdd(&sl->cand_cnt, 1);
-                            if (slot < CAND_CAP) {
-                                sl->cand_idx[slot] = rowK + (16 * mi + rg) * K + unit_perm[16 * (NG * g + nj) + lr];
+                            if (slot < CAND_CAP16) {
+                                tl->cand_i[slot] = rowK + (16 * mi + rg) * K + unit_perm[16 * (NG * g + nj) + lr];
                                 tl->cand_v[slot] = acc[mi][nj][rg];
                             }
                         }
@@ -2944,8 +2949,8 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
         for (int rg = 0; rg < 4; ++rg)
             if (accr[rg] >= tauv) {
                 const int slot = atomicAdd(&sl->cand_cnt, 1);
-                if (slot < CAND_CAP) {
-                    sl->cand_idx[slot] = (rowbase + CSC_TILE_ROWS + 4 * lq + rg) * K + permr;
+                if (slot < CAND_CAP16) {
+                    tl->cand_i[slot] = (rowbase + CSC_TILE_ROWS + 4 * lq + rg) * K + permr;
                     tl->cand_v[slot] = accr[rg];
                 }
             }
@@ -3011,9 +3016,9 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
             if (tid == 0) { *flag = 1; if (a.stats) atomicAdd(&a.stats[3], 1); }
             return;
         }
-        if (sl->cand_cnt > CAND_CAP) {
+        if (sl->cand_cnt > CAND_CAP16) {
             // the list overflowed, perhaps only with entries above an early, lower threshold: once more over the visited
-            // units with the final one (rare); more than CAND_CAP entries in the band itself: fp32
+            // units with the final one (rare); more than CAND_CAP16 entries in the band itself: fp32
             __syncthreads();
             if (tid == 0) sl->cand_cnt = 0;
             for (int i = 0; i < visited; ++i) {
@@ -3022,24 +3027,48 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
                 if (m >= tau) collect(u, tau);
             }
             __syncthreads();
-            if (sl->cand_cnt > CAND_CAP) {
+            if (sl->cand_cnt > CAND_CAP16) {
                 if (tid == 0) { *flag = 1; if (a.stats) atomicAdd(&a.stats[3], 1); }
                 return;
             }
         }
-        // keep the entries within the band of the final maximum (in place; cand_cnt <= 128: one thread)
+        // keep the entries within the band of the final maximum (in place; at most 256: one thread)
         __syncthreads();
         if (tid == 0) {
             const int n = sl->cand_cnt;
             int k = 0;
             for (int q = 0; q < n; ++q)
-                if (tl->cand_v[q] >= tau) sl->cand_idx[k++] = sl->cand_idx[q];
+                if (tl->cand_v[q] >= tau) tl->cand_i[k++] = tl->cand_i[q];
             sl->cand_cnt = k;
         }
         __syncthreads();
-        const int ncand_raw = sl->cand_cnt;
+        const int ncand_all = sl->cand_cnt;
         PROF_MARK(3);
-        rescore_and_choose(a, sl, r64, ncand_raw, false, d);
+        // float64 re-score, CAND_CAP candidates at a time; the choice is the float64 maximum, lowest index first,
+        // over all of them (thread 0 carries the best of the halves)
+        double bestv = -INFINITY;
+        int besti = 0x7fffffff;
+        for (int c0 = 0; c0 < max(ncand_all, 1); c0 += CAND_CAP) {      // (an empty list still goes through the shared code)
+            const int m = min(CAND_CAP, ncand_all - c0);
+            __syncthreads();
+            for (int q = tid; q < m; q += WG) sl->cand_idx[q] = tl->cand_i[c0 + q];
+            __syncthreads();
+            rescore_and_choose(a, sl, r64, m, false, d);
+            if (tid == 0 && sl->beta_ok && (sl->beta > bestv || (sl->beta == bestv && sl->chosen < besti))) {
+                bestv = sl->beta;
+                besti = sl->chosen;
+            }
+        }
+        if (ncand_all > CAND_CAP) {
+            if (tid == 0 && besti != 0x7fffffff) {
+                sl->chosen = besti;
+                sl->sup_pos[d] = besti / K;
+                sl->sup_atom[d] = besti - (besti / K) * K;
+                sl->beta = bestv;
+                sl->beta_ok = 1;
+            }
+            __syncthreads();
+        }
         const int jc = j + t * stride;
         const size_t cid = s * a.NN + a.ts.off[d + 1] + jc;
         if (tid == 0) { tl->sib_pos[t] = sl->sup_pos[d]; tl->sib_atom[t] = sl->sup_atom[d]; }
