@@ -1814,7 +1814,9 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
                         const int r = e / NG, nj = e - r * NG;
                         const int idx = (prow + 16 * (r >> 2) + (r & 3)) * K + sl->perm[16 * (NG * g + nj) + lr];
                         const int slot = atomicAdd(&sl->cand_cnt, 1);
+                        // candidates 128 .. 255 wait in the space of the float64 scores, which nobody has written yet
                         if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
+                        else if (slot < 2 * CAND_CAP) reinterpret_cast<int*>(sl->cand_val)[slot - CAND_CAP] = idx;
                     }
                 }
             }
@@ -1822,8 +1824,33 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
         __syncthreads();
         PROF_MARK(3);
         const int ncand_raw = sl->cand_cnt;
-        if (ncand_raw > CAND_CAP) { give_up(d); return; }             // too many entries in the fp16 band: fp32
-        rescore_and_choose(a, sl, r64, ncand_raw, false, d);
+        if (ncand_raw > 2 * CAND_CAP) { give_up(d); return; }         // too many entries in the fp16 band: fp32
+        if (ncand_raw <= CAND_CAP) {
+            rescore_and_choose(a, sl, r64, ncand_raw, false, d);
+        } else {
+            // a flat residual deep in a tree: 129 .. 256 entries in the band.  The re-score takes them in two halves (the
+            // second half's indices ride in registers while the first half's scores use their space); the choice is the
+            // float64 maximum over both, lowest index first
+            int tq = threadIdx.x;
+            asm volatile("" : "+v"(tq));
+            const int extra = tq < ncand_raw - CAND_CAP ? reinterpret_cast<const int*>(sl->cand_val)[tq] : 0;
+            __syncthreads();
+            rescore_and_choose(a, sl, r64, CAND_CAP, false, d);
+            double v0 = 0.0;
+            int i0 = 0, ok0 = 0;
+            if (tq == 0) { v0 = sl->beta; i0 = sl->chosen; ok0 = sl->beta_ok; }
+            if (tq < ncand_raw - CAND_CAP) sl->cand_idx[tq] = extra;
+            __syncthreads();
+            rescore_and_choose(a, sl, r64, ncand_raw - CAND_CAP, false, d);
+            if (tq == 0 && ok0 && (!sl->beta_ok || v0 > sl->beta || (v0 == sl->beta && i0 < sl->chosen))) {
+                sl->chosen = i0;
+                sl->sup_pos[d] = i0 / K;
+                sl->sup_atom[d] = i0 - (i0 / K) * K;
+                sl->beta = v0;
+                sl->beta_ok = 1;
+            }
+            __syncthreads();
+        }
         PROF_MARK(5);
         const size_t cid = s * a.NN + a.ts.off[d + 1] + j;
         child_solve_and_write(a, sl, r64, s, j, cid, d, nullptr, true);
