@@ -118,7 +118,9 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
  *               settle (multiplied again in fp32; on the single-child levels the rest of the node's chain is
  *               then done in fp32 too)
  *   workspace   csc_mmpdf_workspace_bytes(...) bytes, 16-byte aligned (hipMalloc's are): two generations of node
- *               residuals + one flag byte per frontier node
+ *               residuals + one flag byte per frontier node (dictionaries beyond one register tile: a child's row
+ *               also carries its parent's per-unit screen bounds from the screen kernel to the three-product
+ *               kernel, until the child is written)
  */
 int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,
                     int K, int L, const double* d_signals, int S, int N,
