@@ -614,3 +614,25 @@ def test_torch_custom_ops_match_the_engine(golden_signals):
     # OMP through the op: no similarity table
     pos1, _, _, _ = torch.ops.csc_amd.mmpdf_batch(b32, b64, None, sig, 3, 1, 1, 0)
     assert torch.equal(pos1[:, 0], pos[:, 0])
+
+
+
+def test_reference_defaults_crowded_bands(dic, config2):
+    """The reference's default tree (connections 3, branches 10, max sparsity 10: 92 nodes per signal) on the 3200
+    config-2 signals: deep in the tree the residual is flat and 129 ... 256 entries sit in the fp16 band of the maximum;
+    the chain kernel re-scores them in two halves.  The fp16 path and the fp32-only path must give the same trees, and
+    nearly no chain may be left to the fp32 follow-up kernel (92 per 3200 signals were, when the list held 128)."""
+    sigs = config2[0]
+    bank = dic.device_bank()
+    old = (bank.fp32_only, bank.lean)
+    out = {}
+    try:
+        for name, fp32_only in (("fp16", False), ("fp32", True)):
+            bank.fp32_only, bank.lean = fp32_only, True
+            out[name] = bank.mmpdf_batch(sigs, 10, 3, 10, 0.8, want_coef=False)
+    finally:
+        bank.fp32_only, bank.lean = old
+    a, r = out["fp16"], out["fp32"]
+    assert np.array_equal(a.node_pos, r.node_pos) and np.array_equal(a.node_atom, r.node_atom)
+    assert np.allclose(a.node_mse, r.node_mse, rtol=1e-11, atol=0)
+    assert a.stats[0] == 0 and a.stats[3] <= 10, a.stats
