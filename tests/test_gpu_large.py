@@ -217,6 +217,26 @@ def test_three_product_filter_equals_fp32_path(large_dic):
             assert np.array_equal(getattr(got, name), getattr(ref, name)), (name, len(bank.bank64))
 
 
+
+def test_config3_at_full_size_fp16_front_equals_fp32_path(large_dic):
+    """BASELINE config 3 at the size SURVEY 8(d) asks for: 4096 constrained signals (4 atoms, 10 dB) on the 9570-atom
+    dictionary, c3 / B3 / K5.  The default path (screen + three-product kernels) and the fp32-only path give identical
+    records and node tables, and the fp16 front settles every node itself."""
+    np.random.seed(3)
+    sigs = np.array([large_dic.generateConstrainedTestSignal(777, 4, 10, 10, 0.75)[0] for _ in range(4096)])
+    bank = large_dic.device_bank()
+    try:
+        bank.fp32_only = False
+        got = bank.mmpdf_batch(sigs, 5, 3, 3, 0.8, want_coef=False)
+        bank.fp32_only = True
+        ref = bank.mmpdf_batch(sigs, 5, 3, 3, 0.8, want_coef=False)
+    finally:
+        bank.fp32_only = False
+    assert got.stats[0] == 0 and got.stats[3] <= 4, got.stats
+    for name in ("node_pos", "node_atom", "node_mse", "rec_mse", "rec_leaf", "rec_sel"):
+        assert np.array_equal(getattr(got, name), getattr(ref, name)), name
+
+
 def test_tiled_fp16_front_equals_fp32_on_random_dictionaries():
     """Random dictionaries beyond one register tile (224 ... 1200 atoms; 40 ... 600 positions: one row block with and
     without the 16-row remainder tile, two and three row blocks (one workgroup per CU), partly filled last bank tiles; 1 ... 4 children per node; noisy, noiseless, near-tie and huge
