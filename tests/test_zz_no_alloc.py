@@ -69,3 +69,27 @@ def test_static_scratch_entry_equals_workspace_entry(golden_signals):
     a = bank.mmpdf_launch(small, 5, 3, 3, 0.8, want_coef=False, static_scratch=True)
     b = bank.mmpdf_launch(small, 5, 3, 3, 0.8, want_coef=False)
     assert torch.equal(a["rec_buf"], b["rec_buf"])
+
+
+def test_static_scratch_entry_beyond_one_register_tile():
+    """The same entry point on a dictionary of 330 atoms and 260 positions (screen + three-product fp16 kernels in front
+    of the fp32 tiled kernel: the screen's bounds travel through the static scratch too), two calls in a row, the second
+    smaller: records equal to the workspace entry's."""
+    import torch
+    import csc_amd
+    d = csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.0025), np.arange(0.010, 0.036, 0.0018), [1])
+    bank64 = d.getLocalDictionary()
+    K, L = bank64.shape
+    P = 260
+    rng = np.random.default_rng(3)
+    sigs = 0.02 * rng.standard_normal((48, L + P - 1))
+    for row in sigs:
+        for _ in range(3):
+            row[rng.integers(0, P):][:L] += rng.uniform(0.5, 1.5) * bank64[rng.integers(K)]
+    bank = d.device_bank()
+    for n in (48, 17):
+        sig = torch.from_numpy(np.ascontiguousarray(sigs[:n])).to(bank.device)
+        a = bank.mmpdf_launch(sig, 4, 3, 10, 0.7, want_coef=True, static_scratch=True)
+        b = bank.mmpdf_launch(sig, 4, 3, 10, 0.7, want_coef=True)
+        for name in NAMES:
+            assert torch.equal(a[name], b[name]), (name, n)
