@@ -106,6 +106,7 @@ struct LevelArgs {
     int S;                // signals
     const double* signals;    // [S][N]            } the chain kernels walk several levels: level e reads
     double* ws[2];            // [S][F][NS] each   } signals (e == 0) or ws[e & 1] and writes ws[(e + 1) & 1]
+    int sibling;          // screen16_kernel / mmp_level_tiled16_kernel: the one child (sibling) of each node this launch selects
     int picks_only;       // level 0 ahead of the chain kernel: write the children's (pos, atom) and <atom, signal> only
     int from_root;        // chain kernel: build the level-1 node from the signal and the root level's pick
     TreeShape ts;
@@ -2532,7 +2533,7 @@ __device__ __forceinline__ float fkey_inv(unsigned k) {
 template <bool REM>
 __device__ __forceinline__ void screen_blocks16(const LevelArgs& a, const _Float16* __restrict__ hi_all, unsigned* key,
                                                 const unsigned short* brange, int ntile, int nslab, int nrb,
-                                                const _Float16* rh, int R16T_CS, _Float16* ring) {
+                                                const _Float16* rh, int R16T_CS, _Float16* ring, int nsup, const int* spick) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
@@ -2624,6 +2625,28 @@ __device__ __forceinline__ void screen_blocks16(const LevelArgs& a, const _Float
                 }
             }
 #undef SCREEN_STEP
+            if (nsup > 0 && colok) {
+                // a later sibling: the entries similar to an earlier pick (bit (row - pick position + P - 1) of the pick's
+                // similarity row for this column's atom) take the value 0, as in the reference's mask multiplication
+                const int atom = a.meta[(size_t)p.tile * META_INTS + 16 * p.blk + lr];
+                const int Wd = a.W;
+                for (int q = 0; q < nsup; ++q) {
+                    const uint32_t* srow = a.sim_bits + ((size_t)spick[CSC_MAX_CONNECTIONS + q] * a.K + atom) * Wd;
+                    const int dpb = rowbase + 4 * lq - spick[q] + P - 1;         // bit of (mi, rg) = (0, 0); >= 0
+                    const int w0 = dpb >> 5, b0 = dpb & 31;
+                    uint32_t wd[10];
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) wd[i] = srow[min(w0 + i, Wd - 1)];
+                    // the lane's 272 bits, shifted down so that the bit of (mi, rg) sits at 16 mi + rg
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) wd[i] = __funnelshift_r(wd[i], wd[i + 1], b0);
+#pragma unroll
+                    for (int mi = 0; mi < MTW; ++mi)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg)
+                            if ((wd[mi >> 1] >> (16 * (mi & 1) + rg)) & 1u) acc[mi][rg] = 0.f;
+                }
+            }
             if (rows >= CSC_TILE_ROWS) {                             // (uniform) the 16 main row tiles are all inside
 #pragma unroll
                 for (int mi = 0; mi < 16; mi += 2)
@@ -2734,11 +2757,11 @@ __device__ __forceinline__ float group16x3_finish(const LevelArgs& a, const int*
     return lmax;
 }
 
-// Where a node's screen bounds wait between screen16_kernel and mmp_level_tiled16_kernel: in the workspace row of
-// the node's FIRST child (child t of node j is j + t c^d >= F_d, so no other node's table lives in a row that a child
-// is written to), or, on the last level, which has no child rows, in the node's own row of the idle generation.
-__device__ __forceinline__ float* screen_table(const LevelArgs& a, size_t s, int j, int d) {
-    const size_t row = d + 1 < a.Kmax ? s * a.ts.F[d + 1] + j : s * a.ts.F[d] + j;
+// Where a node's screen bounds for its child t wait between screen16_kernel and mmp_level_tiled16_kernel: in the
+// workspace row of that child, which is written only at the end of the launch that read them, or, on the last level,
+// which has no child rows, in the node's own row of the idle generation (the siblings' launches follow each other).
+__device__ __forceinline__ float* screen_table(const LevelArgs& a, size_t s, int j, int d, int t) {
+    const size_t row = d + 1 < a.Kmax ? s * a.ts.F[d + 1] + j + (size_t)t * a.ts.pw[d] : s * a.ts.F[d] + j;
     return reinterpret_cast<float*>(a.ws[(d + 1) & 1] + row * (size_t)a.NS);
 }
 
@@ -2763,10 +2786,21 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
     _Float16* ring = rh + R16_COPIES * R16T_CS;
     unsigned* key = reinterpret_cast<unsigned*>(ring + TRING * TG_BLK);
     unsigned short* brange = reinterpret_cast<unsigned short*>(key + nunits);
+    int* spick = reinterpret_cast<int*>(brange + ((NT * ntile + 1) & ~1));       // [2][CSC_MAX_CONNECTIONS]: pos, atom
     const int Fd = a.ts.F[d];
     size_t s;
     int j;
     node_of_block(Fd, s, j);
+    // this launch bounds what child t of every node can select: the entries similar to the children picked before it
+    // (launches 0 .. t - 1 of this level) count as 0, as they will in the three-product kernel
+    const int t = a.sibling;
+    if ((long long)j + (long long)t * a.ts.pw[d] >= a.ts.F[d + 1]) return;       // the node has no child t
+    if (t > 0 && a.flags[s * Fd + j]) return;                                    // the node went to the fp32 kernel
+    if (tid < t) {
+        const size_t cid = s * a.NN + a.ts.off[d + 1] + j + (size_t)tid * a.ts.pw[d];
+        spick[tid] = a.node_pos[cid];
+        spick[CSC_MAX_CONNECTIONS + tid] = a.node_atom[cid];
+    }
     const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
     double v = 0.0;
     for (int i = tid; i < N; i += WG) { const double x = rin[i]; v = fma(x, x, v); }
@@ -2794,10 +2828,10 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
     }
     __syncthreads();
     const _Float16* hi_all = reinterpret_cast<const _Float16*>(a.bank16);
-    if (rem) screen_blocks16<true>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring);
-    else screen_blocks16<false>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring);
+    if (rem) screen_blocks16<true>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring, t, spick);
+    else screen_blocks16<false>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring, t, spick);
     __syncthreads();
-    float* tab = screen_table(a, s, j, d);
+    float* tab = screen_table(a, s, j, d, t);
     for (int u = tid; u < nunits; u += WG) tab[u] = fkey_inv(key[u]);
 }
 
@@ -2834,11 +2868,21 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
     for (int r = 0; r < a.connections; ++r) {
         if ((long long)j + (long long)r * stride < Fc) ++nch; else break;
     }
+    uint8_t* flag = a.flags + s * Fd + j;
+    // one launch per child: this one selects child t0 of every node that has one; a node an earlier launch handed to the
+    // fp32 kernel stays there
+    const int t0 = a.sibling;
+    if (t0 >= nch) return;
+    if (t0 > 0 && *flag) return;
     const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
     double rnorm2, first[4];
     node_prologue(a, sl, r64, nullptr, Npad, 0, rin, s, j, rnorm2, first, d);
-    uint8_t* flag = a.flags + s * Fd + j;
-    if (tid == 0) *flag = 0;
+    if (tid == 0 && t0 == 0) *flag = 0;
+    if (tid < t0) {                                                  // the children picked before: suppression
+        const size_t cq = s * a.NN + a.ts.off[d + 1] + j + (size_t)tid * stride;
+        tl->sib_pos[tid] = a.node_pos[cq];
+        tl->sib_atom[tid] = a.node_atom[cq];
+    }
     const float am2 = *a.amax2, am = sqrtf(am2);
     // NaN / Inf / extreme scales: fp32 (workgroup-uniform)
     if (!(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 1e-30 && rnorm2 < 1e30)) {
@@ -2988,7 +3032,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
         // sweep can find there; the units in descending order of that bound
         const float e1 = (9.765625e-4f + 6.103515625e-05f + 1e-6f) * am + 2.98023223876953125e-08f * sqrtf((float)L) * (1.f + am);
         const float slack = (e1 + 0.5f * band) / unscale;
-        const float* tab = screen_table(a, s, j, d);                 // written by screen16_kernel, launched in front
+        const float* tab = screen_table(a, s, j, d, t0);             // written by screen16_kernel, launched in front
         for (int u = tid; u < nunits; u += WG) {
             const float m = tab[u];
             tl->tmax0[u] = m == m ? m + slack : INFINITY;            // (a NaN sorts first and is visited)
@@ -2996,7 +3040,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
 #ifdef CSC_SCREEN_CHECK
         __syncthreads();
         for (int u = 0; u < nunits; ++u) {                            // (equal up to the last bit of the two kernels' ||r||)
-            const float m = unit_max_cold(u, 0, true);
+            const float m = unit_max_cold(u, t0, true);
             if (tid == 0 && m != tab[u] && blockIdx.x < 64)
                 printf("block %d depth %d unit %d of %d: screen kernel %g, per-unit product %g\n", blockIdx.x, d, u, nunits, tab[u], m);
         }
@@ -3014,7 +3058,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
         PROF_MARK(1);
     }
 
-    for (int t = 0; t < nch; ++t) {
+    for (int t = t0; t <= t0; ++t) {
         // ---- the three-product sweep over the units that can reach the band of the running maximum: by descending
         // bound, the first few hold the maximum, and once a unit cannot reach the band no later one can.  Candidates are
         // taken on the way, against the RUNNING maximum: it only rises, so the list is a superset of the entries within
@@ -3571,7 +3615,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
     const int nrb16 = (nrb > 1 && P - (nrb - 1) * CSC_TILE_ROWS <= 16) ? nrb - 1 : nrb;
     const size_t units16 = (size_t)n_tiles(K) * nrb16 * NG;
     const size_t lds_screen = 4 * 8 + (size_t)R16_COPIES * r16t_stride(P, Lp) * 2 + (size_t)TRING * TG_BLK * 2 + units16 * 4 +
-                              (((size_t)n_tiles(K) * NT * 2 + 15) & ~(size_t)15);
+                              (((size_t)n_tiles(K) * NT * 2 + 15) & ~(size_t)15) + 2 * CSC_MAX_CONNECTIONS * 4;
     const bool tiled16 = tiled && !(flags & CSC_FLAG_FP32_ONLY) && node_flags && mode == 0 && L <= 682 &&
                          lds16 <= 150 * 1024 && (long long)n_tiles(K) * nrb * NG <= MAX_UNITS16 && n_tiles(K) * NT <= 2 * MAX_UNITS16 &&
                          lds_screen <= 100 * 1024 && units16 * 4 <= (size_t)(N + TRI(max_sparsity) + max_sparsity) * 8;
@@ -3607,7 +3651,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         if (grid > 0x7fffffffULL) FAIL(-11, "batch too large for one launch (%zu workgroups)", grid);
         const int span = timer_begin(st, d);
         a.flags = nullptr; a.S = S; a.signals = d_signals; a.ws[0] = ws[0]; a.ws[1] = ws[1];
-        a.picks_only = 0; a.from_root = 0;
+        a.picks_only = 0; a.from_root = 0; a.sibling = -1;
         // level 0 in front of the chain kernel (every node of level 1 has one child): it only has to pick -- the chain
         // kernel builds a pick's node from the signal, so no child residual crosses HBM between the two launches
         const bool root_picks = lean && mode == 0 && d == 0 && max_sparsity > 1 && connections > 1 && ts.pw[1] >= ts.F[2];
@@ -3616,8 +3660,16 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
             // the three-product fp16 filter takes the level; the fp32 kernel behind it redoes the flagged nodes
             a.flags = node_flags;
             a.bank16 = bank_tiles16s(d_bank32t, K, L, 0);
-            hipLaunchKernelGGL(screen16_kernel, dim3((unsigned)grid), dim3(WG), lds_screen, st, a);
-            hipLaunchKernelGGL(mmp_level_tiled16_kernel, dim3((unsigned)grid), dim3(WG), lds16, st, a);
+            // one pair of launches per child: the screen bounds child t under the suppression by the children picked
+            // before it, which the launches before have written to the node tables
+            int nsib = 0;
+            for (int r = 0; r < connections; ++r)
+                if ((long long)r * ts.pw[d] < ts.F[d + 1]) ++nsib;
+            for (int t = 0; t < nsib; ++t) {
+                a.sibling = t;
+                hipLaunchKernelGGL(screen16_kernel, dim3((unsigned)grid), dim3(WG), lds_screen, st, a);
+                hipLaunchKernelGGL(mmp_level_tiled16_kernel, dim3((unsigned)grid), dim3(WG), lds16, st, a);
+            }
             a.bank16 = nullptr;
             hipLaunchKernelGGL(mmp_level_tiled_kernel, dim3((unsigned)grid), dim3(WG), lds, st, a);
         } else if (tiled) {
