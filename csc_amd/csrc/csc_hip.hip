@@ -1647,26 +1647,186 @@ __device__ __forceinline__ float group_finish(const LevelArgs& a, const NodeLds*
     return lmax;
 }
 
+// float <-> unsigned key with the same order (for LDS atomicMax on unit maxima)
+__device__ __forceinline__ unsigned fkey(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// ---- the column-owner product of the chain kernel ---------------------------------------------------------------
+// A wave owns whole 16-column tiles of the bank against ALL 16 row tiles (P <= 256): one B fragment and two new A
+// fragments per 16 MFMAs (3 KB of LDS reads instead of the 5 KB per 12 MFMAs of the group loop above), no barrier
+// inside the product, every wave streaming its own tiles L2 -> LDS through a private ring (the pattern of the
+// large-dictionary screen, screen_blocks16).  The nine column tiles are dealt to the four waves longest first
+// (ColsLds::witem, by live slabs).  A finished tile is complete in registers, so its candidates are taken at once,
+// against the node's running maximum (an LDS atomicMax; a lower bound of the final maximum, so the entries kept are a
+// superset), value beside index; the chain filters them by the final band behind the product's one barrier: one
+// sweep, nothing multiplied twice.
+#define LEAN_AHEAD 6                   // ring slots (1 KiB blocks) per wave
+#define RAW_CAP 512
+struct ColsLds {
+    unsigned short crange[NT + 1];     // per column tile: first live slab | one past the last << 8
+    unsigned short order[NT + 1];      // column tiles by falling number of live slabs: tile | slabs << 8
+    unsigned char witem[WG / 64][NT + 3];   // per wave: number of tiles, then the tiles
+    unsigned gkey;                     // running maximum of the node's filter product (fkey)
+    int raw_cnt;
+    int raw_idx[RAW_CAP];
+    float raw_val[RAW_CAP];
+};
+
+__device__ __forceinline__ void lean_cols16(const LevelArgs& a, const NodeLds* sl, ColsLds* cl, const _Float16* r16,
+                                            _Float16* ring, float band) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int P = a.P, K = a.K;
+    _Float16* myring = ring + wave * (LEAN_AHEAD * BLKF);
+    const unsigned char* items = cl->witem[wave];
+    const int nit = __builtin_amdgcn_readfirstlane((int)items[0]);
+    auto item_range = [&](int c, int& s0, int& s1) {
+        const int pk = __builtin_amdgcn_readfirstlane((int)cl->crange[c]);
+        s0 = pk & 0xff;
+        s1 = pk >> 8;
+    };
+    // the wave's stream of B blocks: the copy cursor runs LEAN_AHEAD slabs ahead of the multiplication, across tiles
+    int ci = 0, cs = 0, ce = 0, cslot = 0;
+    bool more = true;
+    const _Float16* cb = a.bank16;
+    auto cursor_copy = [&]() {
+        while (cs >= ce) {
+            if (!more) return;
+            if (ci >= nit) { more = false; return; }
+            const int c = __builtin_amdgcn_readfirstlane((int)items[1 + ci]);
+            ++ci;
+            item_range(c, cs, ce);
+            cb = a.bank16 + c * BLKF + lane * 8;
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)(cb + (size_t)cs * SLABF), (lptr_t)(myring + cslot * BLKF), 16, 0, 0);
+        ++cs;
+        cslot = cslot == LEAN_AHEAD - 1 ? 0 : cslot + 1;
+    };
+    WAIT_VM(0);
+#pragma unroll
+    for (int i = 0; i < LEAN_AHEAD; ++i) cursor_copy();
+    f16x8 W[20], b[2];
+    f32x4 acc[16];
+    int slot = 0;
+    if (more) WAIT_VM(LEAN_AHEAD - 1); else WAIT_VM(0);
+    b[0] = *reinterpret_cast<const f16x8*>(myring + lane * 8);
+    const _Float16* pa = r16 + (lr & 7) * R16_CS + (lr & 8) + 8 * lq;
+    // one slab: slab s of a tile that starts at s0 multiplies the window fragments 2 (s - s0) + 0 .. 15, kept in
+    // eighteen registers in rotation (the two of slab s + 1 that slab s does not use are read here)
+    auto body = [&](auto phc, auto firstc, int s) {
+        constexpr int PH = decltype(phc)::value;
+        constexpr bool FIRST = decltype(firstc)::value;
+        if (more) WAIT_VM(LEAN_AHEAD - 2); else WAIT_VM(0);
+        const int nslot = slot == LEAN_AHEAD - 1 ? 0 : slot + 1;
+        b[(PH + 1) & 1] = *reinterpret_cast<const f16x8*>(myring + nslot * BLKF + lane * 8);
+        W[(2 * PH + 16) % 20] = *reinterpret_cast<const f16x8*>(pa + 32 * s + 16 * 16);
+        W[(2 * PH + 17) % 20] = *reinterpret_cast<const f16x8*>(pa + 32 * s + 16 * 17);
+#pragma unroll
+        for (int mi = 0; mi < 16; ++mi)
+            acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[(2 * PH + mi) % 20], b[PH & 1],
+                                                             FIRST ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mi], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cursor_copy();
+        slot = nslot;
+    };
+    for (int it = 0; it < nit; ++it) {
+        const int c = __builtin_amdgcn_readfirstlane((int)items[1 + it]);
+        int s0, s1;
+        item_range(c, s0, s1);
+        const int atom = sl->perm[16 * c + lr];
+        if (s0 >= s1) {
+            if (atom >= 0) atomicAdd(&cl->raw_cnt, RAW_CAP + 1);
+            continue;
+        }
+        {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) W[i] = *reinterpret_cast<const f16x8*>(pa + 32 * s0 + 16 * i);
+            int s = s0;
+#define COLS_STEP(PH) body(std::integral_constant<int, PH>{}, std::false_type{}, s); \
+            if (++s >= s1) { if (((PH) & 1) == 0) b[0] = b[1]; break; }
+            body(std::integral_constant<int, 0>{}, std::true_type{}, s);
+            if (++s >= s1) {
+                b[0] = b[1];
+            } else {
+                while (true) {
+                    COLS_STEP(1) COLS_STEP(2) COLS_STEP(3) COLS_STEP(4) COLS_STEP(5)
+                    COLS_STEP(6) COLS_STEP(7) COLS_STEP(8) COLS_STEP(9) COLS_STEP(0)
+                }
+            }
+#undef COLS_STEP
+        }
+        // the tile's 256 x 16 correlations are complete: rows >= P and padding columns out, maximum, candidates
+        float lmax = -INFINITY;
+#pragma unroll
+        for (int mi = 0; mi < 16; ++mi) {
+            if (16 * mi + 15 >= P) {                                 // (uniform)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    if (16 * mi + 4 * lq + rg >= P) acc[mi][rg] = -INFINITY;
+            }
+            lmax = fmaxf(lmax, fmaxf(fmaxf(acc[mi][0], acc[mi][1]), fmaxf(acc[mi][2], acc[mi][3])));
+        }
+        if (atom < 0) lmax = -INFINITY;
+        float bm = wave_max(lmax);
+        bm = bm == bm ? bm : INFINITY;
+        unsigned cur = 0;
+        if (lane == 63) {
+            const unsigned mine = fkey(bm);
+            const unsigned old = atomicMax(&cl->gkey, mine);
+            cur = old > mine ? old : mine;
+        }
+        const float tauw = fkey_inv((unsigned)__builtin_amdgcn_readlane((int)cur, 63)) - band;
+        if (lmax >= tauw) {
+#pragma unroll
+            for (int mi = 0; mi < 16; ++mi) {
+                const f32x4 v4 = acc[mi];
+                uint32_t mm = (v4[0] >= tauw ? 1u : 0u) | (v4[1] >= tauw ? 2u : 0u) | (v4[2] >= tauw ? 4u : 0u) |
+                              (v4[3] >= tauw ? 8u : 0u);
+                while (mm) {
+                    const int rg = __builtin_ctz(mm);
+                    mm &= mm - 1;
+                    const float v = rg == 0 ? v4[0] : (rg == 1 ? v4[1] : (rg == 2 ? v4[2] : v4[3]));
+                    const int at = atomicAdd(&cl->raw_cnt, 1);
+                    if (at < RAW_CAP) {
+                        cl->raw_idx[at] = (16 * mi + 4 * lq + rg) * K + atom;
+                        cl->raw_val[at] = v;
+                    }
+                }
+            }
+        }
+    }
+    WAIT_VM(0);
+}
+
 struct LeanLds {
     float wgmax[NT / NG][WG / 64];     // sweep 1: maximum of each group per wave
     int sib_pos[1], sib_atom[1];       // (no siblings on the chain levels: group_finish is called with t = 0)
     int s0[NT / NG], s1[NT / NG];      // slab range of each group (outside it the group's blocks are zero padding)
 };
 
-__global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a) {
+template <bool COLS>
+__device__ __forceinline__ void lean_chain(const LevelArgs& a) {
     extern __shared__ double lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int N = a.N, K = a.K, L = a.L, d0 = a.depth;
     const int nslab = (L + SLAB - 1) / SLAB;
 
-    // ---- LDS carve-up: ring [LRING][GBLK] halves | r64 [Npad] | r16 [R16_COPIES][R16_CS] | NodeLds | LeanLds
+    // ---- LDS carve-up: ring [LRING][GBLK] halves (COLS: [4 waves][LEAN_AHEAD][BLKF]) | r64 [Npad] |
+    // r16 [R16_COPIES][R16_CS] | NodeLds | LeanLds | COLS: ColsLds
     const int Npad = (N + 3) & ~3;
     _Float16* ring = reinterpret_cast<_Float16*>(lds_raw);
-    double* r64 = lds_raw + (LRING * GBLK) / 4;
+    double* r64 = lds_raw + (COLS ? (WG / 64) * LEAN_AHEAD * BLKF : LRING * GBLK) / 4;
     _Float16* r16 = reinterpret_cast<_Float16*>(r64 + Npad);
     NodeLds* sl = reinterpret_cast<NodeLds*>(r16 + R16_COPIES * R16_CS);
     LeanLds* ll = reinterpret_cast<LeanLds*>(sl + 1);
+    ColsLds* cl = reinterpret_cast<ColsLds*>(ll + 1);
 
     const int Fd = a.ts.F[d0];                                        // = F of every level below (one child per node)
     size_t s;
@@ -1674,6 +1834,13 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
     node_of_block(Fd, s, j);
     if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
     if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
+    if (COLS && tid < NT) {
+        // live slabs of column tile `tid` (outside them its blocks are zero padding)
+        int lo = nslab, hi = 0;
+        for (int q = 0; q < nslab; ++q)
+            if (((uint32_t)a.meta[CSC_TILE_COLS + q] >> tid) & 1u) { lo = min(lo, q); hi = q + 1; }
+        cl->crange[tid] = (unsigned short)(min(lo, hi) | (hi << 8));
+    }
 
     PROF_INIT(16);
     const double* rin = (d0 == 0 || a.from_root) ? a.signals + s * (size_t)N : a.ws[d0 & 1] + (s * Fd + j) * (size_t)a.NS;
@@ -1701,7 +1868,34 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
     const float am2 = *a.amax2, am = sqrtf(am2);
     const float band = 2.f * ((9.765625e-04f + DELTA_REL + 1e-6f) * am + 2.9802322e-08f * sqrtf((float)L) * (1.f + am));
     if (tid == 0) a.flags[s * Fd + j] = 0;
-    if (tid < NT / NG) {
+    if (COLS) {
+        // the column tiles by falling number of live slabs, dealt longest first to the least loaded wave
+        if (tid < NT) {
+            const int pk = cl->crange[tid], len = (pk >> 8) - (pk & 0xff);
+            int rank = 0;
+            for (int c = 0; c < NT; ++c) {
+                const int pc = cl->crange[c], lc = (pc >> 8) - (pc & 0xff);
+                rank += (lc > len || (lc == len && c < tid)) ? 1 : 0;
+            }
+            cl->order[rank] = (unsigned short)(tid | (len << 8));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int load[WG / 64] = {0, 0, 0, 0}, cnt[WG / 64] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int o = cl->order[i];
+                int w = 0;
+#pragma unroll
+                for (int q = 1; q < WG / 64; ++q) w = load[q] < load[w] ? q : w;
+#pragma unroll
+                for (int q = 0; q < WG / 64; ++q)
+                    if (q == w) { cl->witem[q][1 + cnt[q]] = (unsigned char)(o & 0xff); ++cnt[q]; load[q] += (o >> 8) + 1; }
+            }
+#pragma unroll
+            for (int q = 0; q < WG / 64; ++q) cl->witem[q][0] = (unsigned char)cnt[q];
+        }
+    } else if (tid < NT / NG) {
         // group g's blocks hold a non-zero only in slabs whose first non-zero tile is below 3 (g + 1)
         int lo = nslab, hi = 0;
         for (int q = 0; q < nslab; ++q) {
@@ -1744,80 +1938,110 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
         // NaN / Inf / extreme scales: fp32
         if (!(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 1e-30 && rnorm2 < 1e30)) { give_up(d); return; }
         build_r16(r64, N, (float)(1.0 / sqrt(rnorm2)), first, r16);
+        if (COLS && tid == 0) { sl->cand_cnt = 0; cl->raw_cnt = 0; cl->gkey = fkey(-INFINITY); }
         __syncthreads();
 #ifdef CSC_PHASE_PROF
         const unsigned trace_t0 = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
-        // ---- sweep 1: group maxima -----------------------------------------------------------------------
-        // widest atoms first, narrowest last: the last group stays in registers for sweep 2, and the narrow atoms'
-        // group is both the one that most often holds the maximum (2 of 3 nodes on config 2) and the cheapest
-        for (int g = NT / NG - 1; g >= 0; --g) {
-            bool lane_supp;
-            gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
-            const float lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, 0, permv, acc, lane_supp);
-            const float bv = wave_max(lmax);
-            if (lane == 63) ll->wgmax[g][wave] = bv;                  // read behind the barrier below
-        }
-        if (tid == 0) sl->cand_cnt = 0;
-        __syncthreads();
-        float gmax[NT / NG];
-#pragma unroll
-        for (int g = 0; g < NT / NG; ++g)
-            gmax[g] = fmaxf(fmaxf(ll->wgmax[g][0], ll->wgmax[g][1]), fmaxf(ll->wgmax[g][2], ll->wgmax[g][3]));
-        PROF_MARK(1);
+        if constexpr (COLS) {
+            // ---- one sweep, a wave per column tile; candidates against the running maximum ------------------------
+            lean_cols16(a, sl, cl, r16, ring, band);
+            __syncthreads();
+            PROF_MARK(1);
 #ifdef CSC_PHASE_PROF
-        if (tid == 0) {
-            const unsigned at = atomicAdd(&g_trace_n, 1u);
-            if (at < TRACE_CAP) {
-                g_trace[at][0] = __builtin_amdgcn_s_getreg(63492);
-                g_trace[at][1] = trace_t0;
-                g_trace[at][2] = (unsigned)__builtin_amdgcn_s_memtime();
-                g_trace[at][3] = blockIdx.x | ((__builtin_amdgcn_s_getreg(6164) & 15u) << 24) | ((unsigned)d << 28);
+            if (tid == 0) {
+                const unsigned at = atomicAdd(&g_trace_n, 1u);
+                if (at < TRACE_CAP) {
+                    g_trace[at][0] = __builtin_amdgcn_s_getreg(63492);
+                    g_trace[at][1] = trace_t0;
+                    g_trace[at][2] = (unsigned)__builtin_amdgcn_s_memtime();
+                    g_trace[at][3] = blockIdx.x | ((__builtin_amdgcn_s_getreg(6164) & 15u) << 24) | ((unsigned)d << 28);
+                }
             }
-        }
 #endif
-        const float m32 = fmaxf(fmaxf(gmax[0], gmax[1]), gmax[2]);
-        const float tau = m32 - band;
-        // ---- sweep 2: candidates from the groups that reach the band; the last group is still in registers --
-        for (int g = 0; g < NT / NG; ++g) {
-            if (!(gmax[g] >= tau)) continue;                          // uniform
-            bool lane_supp;
-            float lmax;
-            if (g != 0) {
+            const int nraw = cl->raw_cnt;
+            if (nraw > RAW_CAP) { give_up(d); return; }               // (uniform) a flat residual: fp32
+            const float tau = fkey_inv(cl->gkey) - band;
+            int tq = threadIdx.x;
+            asm volatile("" : "+v"(tq));
+            for (int i = tq; i < nraw; i += WG)
+                if (cl->raw_val[i] >= tau) {
+                    const int slot = atomicAdd(&sl->cand_cnt, 1);
+                    if (slot < CAND_CAP) sl->cand_idx[slot] = cl->raw_idx[i];
+                    else if (slot < 2 * CAND_CAP) reinterpret_cast<int*>(sl->cand_val)[slot - CAND_CAP] = cl->raw_idx[i];
+                }
+        } else {
+            // ---- sweep 1: group maxima -----------------------------------------------------------------------
+            // widest atoms first, narrowest last: the last group stays in registers for sweep 2, and the narrow atoms'
+            // group is both the one that most often holds the maximum (2 of 3 nodes on config 2) and the cheapest
+            for (int g = NT / NG - 1; g >= 0; --g) {
+                bool lane_supp;
                 gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
-                lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, 0, permv, acc, lane_supp);
-            } else {
-                lmax = -INFINITY;
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                    for (int nj = 0; nj < NG; ++nj)
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) lmax = fmaxf(lmax, acc[mi][nj][rg]);
+                const float lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, 0, permv, acc, lane_supp);
+                const float bv = wave_max(lmax);
+                if (lane == 63) ll->wgmax[g][wave] = bv;                  // read behind the barrier below
             }
-            if (lmax >= tau) {
-                uint32_t mk[2] = {0u, 0u};
+            if (tid == 0) sl->cand_cnt = 0;
+            __syncthreads();
+            float gmax[NT / NG];
 #pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
+            for (int g = 0; g < NT / NG; ++g)
+                gmax[g] = fmaxf(fmaxf(ll->wgmax[g][0], ll->wgmax[g][1]), fmaxf(ll->wgmax[g][2], ll->wgmax[g][3]));
+            PROF_MARK(1);
+#ifdef CSC_PHASE_PROF
+            if (tid == 0) {
+                const unsigned at = atomicAdd(&g_trace_n, 1u);
+                if (at < TRACE_CAP) {
+                    g_trace[at][0] = __builtin_amdgcn_s_getreg(63492);
+                    g_trace[at][1] = trace_t0;
+                    g_trace[at][2] = (unsigned)__builtin_amdgcn_s_memtime();
+                    g_trace[at][3] = blockIdx.x | ((__builtin_amdgcn_s_getreg(6164) & 15u) << 24) | ((unsigned)d << 28);
+                }
+            }
+#endif
+            const float m32 = fmaxf(fmaxf(gmax[0], gmax[1]), gmax[2]);
+            const float tau = m32 - band;
+            // ---- sweep 2: candidates from the groups that reach the band; the last group is still in registers --
+            for (int g = 0; g < NT / NG; ++g) {
+                if (!(gmax[g] >= tau)) continue;                          // uniform
+                bool lane_supp;
+                float lmax;
+                if (g != 0) {
+                    gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
+                    lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, 0, permv, acc, lane_supp);
+                } else {
+                    lmax = -INFINITY;
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg)
+                    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                        for (int nj = 0; nj < NG; ++nj) {
-                            const int e = (4 * mi + rg) * NG + nj;
-                            mk[e >> 5] |= (acc[mi][nj][rg] >= tau) ? (1u << (e & 31)) : 0u;
+                        for (int nj = 0; nj < NG; ++nj)
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg) lmax = fmaxf(lmax, acc[mi][nj][rg]);
+                }
+                if (lmax >= tau) {
+                    uint32_t mk[2] = {0u, 0u};
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                            for (int nj = 0; nj < NG; ++nj) {
+                                const int e = (4 * mi + rg) * NG + nj;
+                                mk[e >> 5] |= (acc[mi][nj][rg] >= tau) ? (1u << (e & 31)) : 0u;
+                            }
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        uint32_t mm = mk[w];
+                        while (mm) {
+                            const int e = 32 * w + __builtin_ctz(mm);
+                            mm &= mm - 1;
+                            const int r = e / NG, nj = e - r * NG;
+                            const int idx = (prow + 16 * (r >> 2) + (r & 3)) * K + sl->perm[16 * (NG * g + nj) + lr];
+                            const int slot = atomicAdd(&sl->cand_cnt, 1);
+                            // candidates 128 .. 255 wait in the space of the float64 scores, which nobody has written yet
+                            if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
+                            else if (slot < 2 * CAND_CAP) reinterpret_cast<int*>(sl->cand_val)[slot - CAND_CAP] = idx;
                         }
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    uint32_t mm = mk[w];
-                    while (mm) {
-                        const int e = 32 * w + __builtin_ctz(mm);
-                        mm &= mm - 1;
-                        const int r = e / NG, nj = e - r * NG;
-                        const int idx = (prow + 16 * (r >> 2) + (r & 3)) * K + sl->perm[16 * (NG * g + nj) + lr];
-                        const int slot = atomicAdd(&sl->cand_cnt, 1);
-                        // candidates 128 .. 255 wait in the space of the float64 scores, which nobody has written yet
-                        if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
-                        else if (slot < 2 * CAND_CAP) reinterpret_cast<int*>(sl->cand_val)[slot - CAND_CAP] = idx;
                     }
                 }
             }
@@ -1860,6 +2084,10 @@ __global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a
     }
     PROF_MARK(9);
 }
+
+__global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a) { lean_chain<false>(a); }
+// the same chain with the column-owner product: 64 accumulator + 80 window registers, three workgroups per CU
+__global__ __launch_bounds__(WG, 3) void mmp_level_cols_kernel(const LevelArgs a) { lean_chain<true>(a); }
 
 // ------------------------------------------------------------------------------------------------
 // test aid: the fp16 filter product itself (what the level kernels only ever hold in registers)
@@ -2509,15 +2737,6 @@ __device__ __forceinline__ void gemm16x1_group(const _Float16* __restrict__ hi, 
     __syncthreads();
 }
 #endif
-
-// float <-> unsigned key with the same order (for LDS atomicMax on unit maxima)
-__device__ __forceinline__ unsigned fkey(float f) {
-    const unsigned b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float fkey_inv(unsigned k) {
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
 
 // The screen of a whole node, without a barrier: every wave works on its own -- wave w takes the 16-column blocks
 // q = w, w + 4, ... (q = block + 9 (bank tile + ntile * row block)) against ALL the row tiles of the row block (16, or 17
@@ -3556,8 +3775,9 @@ static size_t node_ws_bytes(int S, int N, int max_sparsity, const TreeShape& ts)
 static size_t flag_ws_bytes(int S, int max_sparsity, const TreeShape& ts) {      // one byte per frontier node
     return ((size_t)S * frontier_max(max_sparsity, ts) + 15) & ~(size_t)15;
 }
-static size_t lean_lds_bytes(int N) {
-    return (size_t)LRING * GBLK * 2 + (size_t)ceil4(N) * 8 + R16_COPIES * R16_CS * 2 + sizeof(NodeLds) + sizeof(LeanLds);
+static size_t lean_lds_bytes(int N, bool cols) {
+    return (cols ? (size_t)(WG / 64) * LEAN_AHEAD * BLKF * 2 + sizeof(ColsLds) : (size_t)LRING * GBLK * 2) +
+           (size_t)ceil4(N) * 8 + R16_COPIES * R16_CS * 2 + sizeof(NodeLds) + sizeof(LeanLds);
 }
 
 size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections, int branches) {
@@ -3628,6 +3848,8 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (!tiled) hipFuncSetAttribute((const void*)mmp_level_followup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds);
+    if (lean) hipFuncSetAttribute((const void*)mmp_level_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lean_lds_bytes(N, true));
 
     double* ws[2] = {static_cast<double*>(d_workspace), static_cast<double*>(d_workspace) + node_bytes / 16};
     hipStream_t st = (hipStream_t)stream;
@@ -3688,7 +3910,12 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
             a.flags = node_flags;
             a.from_root = picked ? 1 : 0;
             chain = true;
-            hipLaunchKernelGGL(mmp_level_lean_kernel, dim3((unsigned)grid), dim3(WG), lean_lds_bytes(N), st, a);
+            // CSC_FLAG_LEAN_COLS: the same chain with the column-owner product (an experiment that lost, DESIGN.md §9;
+            // identical records)
+            if (flags & CSC_FLAG_LEAN_COLS)
+                hipLaunchKernelGGL(mmp_level_cols_kernel, dim3((unsigned)grid), dim3(WG), lean_lds_bytes(N, true), st, a);
+            else
+                hipLaunchKernelGGL(mmp_level_lean_kernel, dim3((unsigned)grid), dim3(WG), lean_lds_bytes(N, false), st, a);
             hipLaunchKernelGGL(mmp_level_followup_kernel, dim3((unsigned)((grid + FOLLOW_NODES - 1) / FOLLOW_NODES)),
                                dim3(WG), lds, st, a);                // the chains it gave up: fp32
         } else {

@@ -34,6 +34,7 @@ extern "C" {
 #define CSC_FLAG_FP32_ONLY 1   /* csc_mmpdf_batch flags: skip the fp16 matrix-core filter      */
 #define CSC_FLAG_NO_LEAN 2     /* keep single-child levels on the register-resident kernel      */
 #define CSC_FLAG_RECORDS_AOS 4 /* per-sparsity records as one contiguous record per signal      */
+#define CSC_FLAG_LEAN_COLS 8   /* chain kernel: the column-owner product (experiment, same records) */
 #define CSC_STATIC_SCRATCH_BYTES (64u << 20)   /* static device scratch of csc_mmpdf_batch_static      */
 
 int csc_abi_version(void);
@@ -95,6 +96,8 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
  *               that takes the fp16 product in three column groups (four nodes per CU instead of two) and
  *               walks each chain of such nodes down to its leaf in one launch; the flag keeps them on the
  *               register-resident kernel, one launch per level (identical results, same purpose)
+ *               CSC_FLAG_LEAN_COLS: those chains with the column-owner product (a wave per 16-column bank tile
+ *               against all row tiles; an experiment kept for comparison: identical results, slower)
  *   d_signals   [S][N] f64
  *   d_node_pos  [S][NN] int32   selected position of the node      (src/csc/mmp.py:74-76)
  *   d_node_atom [S][NN] int32   selected atom index
