@@ -1808,6 +1808,7 @@ struct LeanLds {
     float wgmax[NT / NG][WG / 64];     // sweep 1: maximum of each group per wave
     int sib_pos[1], sib_atom[1];       // (no siblings on the chain levels: group_finish is called with t = 0)
     int s0[NT / NG], s1[NT / NG];      // slab range of each group (outside it the group's blocks are zero padding)
+    unsigned gkey;                     // running maximum of the node's filter product (fkey)
 };
 
 template <bool COLS>
@@ -1938,7 +1939,10 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
         // NaN / Inf / extreme scales: fp32
         if (!(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 1e-30 && rnorm2 < 1e30)) { give_up(d); return; }
         build_r16(r64, N, (float)(1.0 / sqrt(rnorm2)), first, r16);
-        if (COLS && tid == 0) { sl->cand_cnt = 0; cl->raw_cnt = 0; cl->gkey = fkey(-INFINITY); }
+        if (tid == 0) {
+            sl->cand_cnt = 0;
+            if (COLS) { cl->raw_cnt = 0; cl->gkey = fkey(-INFINITY); } else ll->gkey = fkey(-INFINITY);
+        }
         __syncthreads();
 #ifdef CSC_PHASE_PROF
         const unsigned trace_t0 = (unsigned)__builtin_amdgcn_s_memtime();
@@ -1971,17 +1975,67 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
                     else if (slot < 2 * CAND_CAP) reinterpret_cast<int*>(sl->cand_val)[slot - CAND_CAP] = cl->raw_idx[i];
                 }
         } else {
-            // ---- sweep 1: group maxima -----------------------------------------------------------------------
-            // widest atoms first, narrowest last: the last group stays in registers for sweep 2, and the narrow atoms'
-            // group is both the one that most often holds the maximum (2 of 3 nodes on config 2) and the cheapest
-            for (int g = NT / NG - 1; g >= 0; --g) {
+            // ---- ONE sweep: a group's candidates are taken while it is in registers, against the node's running maximum
+            // (the groups before, and this wave's own share of this one: a lower bound of the final maximum, so the
+            // entries kept are a superset), value beside index; the final band filters them behind the sweep.  Narrow
+            // atoms first: their group holds the maximum most often (2 of 3 nodes on config 2), which keeps the early
+            // thresholds tight.  Only when more than CAND_CAP entries pass the early thresholds is there a second sweep
+            // with the final one (the round-1 scheme: every group in the band multiplied again)
+            auto collect = [&](int g, float thr, bool early) {
+                uint32_t mk[2] = {0u, 0u};
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                        for (int nj = 0; nj < NG; ++nj) {
+                            const int e = (4 * mi + rg) * NG + nj;
+                            mk[e >> 5] |= (acc[mi][nj][rg] >= thr) ? (1u << (e & 31)) : 0u;
+                        }
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    uint32_t mm = mk[w];
+                    while (mm) {
+                        const int e = 32 * w + __builtin_ctz(mm);
+                        mm &= mm - 1;
+                        const int r = e / NG, nj = e - r * NG;
+                        const int idx = (prow + 16 * (r >> 2) + (r & 3)) * K + sl->perm[16 * (NG * g + nj) + lr];
+                        const int slot = atomicAdd(&sl->cand_cnt, 1);
+                        if (early) {
+                            float v = 0.f;
+#pragma unroll
+                            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                                for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                                    for (int n2 = 0; n2 < NG; ++n2) v = (e == (4 * mi + rg) * NG + n2) ? acc[mi][n2][rg] : v;
+                            if (slot < CAND_CAP) {
+                                sl->cand_idx[slot] = idx;
+                                reinterpret_cast<float*>(sl->cand_val)[slot] = v;
+                            }
+                        } else {
+                            // candidates 128 .. 255 wait in the space of the float64 scores, which nobody has written yet
+                            if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
+                            else if (slot < 2 * CAND_CAP) reinterpret_cast<int*>(sl->cand_val)[slot - CAND_CAP] = idx;
+                        }
+                    }
+                }
+            };
+            for (int g = 0; g < NT / NG; ++g) {
                 bool lane_supp;
                 gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
                 const float lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, 0, permv, acc, lane_supp);
                 const float bv = wave_max(lmax);
-                if (lane == 63) ll->wgmax[g][wave] = bv;                  // read behind the barrier below
+                unsigned cur = 0;
+                if (lane == 63) {
+                    ll->wgmax[g][wave] = bv;                              // read behind the barrier below
+                    const unsigned mine = fkey(bv == bv ? bv : -INFINITY);
+                    const unsigned old = atomicMax(&ll->gkey, mine);
+                    cur = old > mine ? old : mine;
+                }
+                const float tauw = fkey_inv((unsigned)__builtin_amdgcn_readlane((int)cur, 63)) - band;
+                if (lmax >= tauw) collect(g, tauw, true);
             }
-            if (tid == 0) sl->cand_cnt = 0;
             __syncthreads();
             float gmax[NT / NG];
 #pragma unroll
@@ -2001,48 +2055,39 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
 #endif
             const float m32 = fmaxf(fmaxf(gmax[0], gmax[1]), gmax[2]);
             const float tau = m32 - band;
-            // ---- sweep 2: candidates from the groups that reach the band; the last group is still in registers --
-            for (int g = 0; g < NT / NG; ++g) {
-                if (!(gmax[g] >= tau)) continue;                          // uniform
-                bool lane_supp;
-                float lmax;
-                if (g != 0) {
-                    gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
-                    lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, 0, permv, acc, lane_supp);
-                } else {
-                    lmax = -INFINITY;
+            const int nraw = sl->cand_cnt;
+            int tq = threadIdx.x;
+            asm volatile("" : "+v"(tq));
+            if (nraw <= CAND_CAP) {                                       // (uniform) the early entries, by the final band
+                int keep = -1;
+                if (tq < nraw && reinterpret_cast<const float*>(sl->cand_val)[tq] >= tau) keep = sl->cand_idx[tq];
+                __syncthreads();
+                if (tq == 0) sl->cand_cnt = 0;
+                __syncthreads();
+                if (keep >= 0) sl->cand_idx[atomicAdd(&sl->cand_cnt, 1)] = keep;
+            } else {
+                // ---- sweep 2: candidates from the groups that reach the band; the last group is still in registers
+                __syncthreads();                                          // (everybody has read nraw)
+                if (tq == 0) sl->cand_cnt = 0;
+                __syncthreads();
+                for (int gi = 0; gi < NT / NG; ++gi) {
+                    const int g = gi == 0 ? NT / NG - 1 : gi - 1;
+                    if (!(gmax[g] >= tau)) continue;                      // uniform
+                    bool lane_supp;
+                    float lmax;
+                    if (gi != 0) {
+                        gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
+                        lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, 0, permv, acc, lane_supp);
+                    } else {
+                        lmax = -INFINITY;
 #pragma unroll
-                    for (int mi = 0; mi < MT; ++mi)
+                        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                        for (int nj = 0; nj < NG; ++nj)
+                            for (int nj = 0; nj < NG; ++nj)
 #pragma unroll
-                            for (int rg = 0; rg < 4; ++rg) lmax = fmaxf(lmax, acc[mi][nj][rg]);
-                }
-                if (lmax >= tau) {
-                    uint32_t mk[2] = {0u, 0u};
-#pragma unroll
-                    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-                            for (int nj = 0; nj < NG; ++nj) {
-                                const int e = (4 * mi + rg) * NG + nj;
-                                mk[e >> 5] |= (acc[mi][nj][rg] >= tau) ? (1u << (e & 31)) : 0u;
-                            }
-#pragma unroll
-                    for (int w = 0; w < 2; ++w) {
-                        uint32_t mm = mk[w];
-                        while (mm) {
-                            const int e = 32 * w + __builtin_ctz(mm);
-                            mm &= mm - 1;
-                            const int r = e / NG, nj = e - r * NG;
-                            const int idx = (prow + 16 * (r >> 2) + (r & 3)) * K + sl->perm[16 * (NG * g + nj) + lr];
-                            const int slot = atomicAdd(&sl->cand_cnt, 1);
-                            // candidates 128 .. 255 wait in the space of the float64 scores, which nobody has written yet
-                            if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
-                            else if (slot < 2 * CAND_CAP) reinterpret_cast<int*>(sl->cand_val)[slot - CAND_CAP] = idx;
-                        }
+                                for (int rg = 0; rg < 4; ++rg) lmax = fmaxf(lmax, acc[mi][nj][rg]);
                     }
+                    if (lmax >= tau) collect(g, tau, false);
                 }
             }
         }
