@@ -1846,7 +1846,6 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
     PROF_INIT(16);
     const double* rin = (d0 == 0 || a.from_root) ? a.signals + s * (size_t)N : a.ws[d0 & 1] + (s * Fd + j) * (size_t)a.NS;
     double rnorm2, first[4];
-    bool reload_first = false;
     node_prologue(a, sl, r64, nullptr, Npad, 0, rin, s, j, rnorm2, first, a.from_root ? 0 : d0);
     if (a.from_root) {
         // d0 = 1 and the root level left only its pick: this node is the signal's child (pos, atom) with <atom, signal>
@@ -1863,7 +1862,6 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
         child_solve_and_write(a, sl, r64, s, j, cid, 0, nullptr, true);
         __syncthreads();
         rnorm2 = sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3];
-        reload_first = true;
     }
     PROF_MARK(0);
     const float am2 = *a.amax2, am = sqrtf(am2);
@@ -1927,18 +1925,22 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
     // ---- the chain: this node, its child, its grandchild ... down to the leaves; the residual, the Cholesky
     // factor and the coefficients stay in LDS from one level to the next, only the node tables go to HBM
     for (int d = d0; d < a.Kmax; ++d) {
-        if (d > d0 || reload_first) {                                 // the window elements build_r16 wants in registers
+        // NaN / Inf / extreme scales: fp32
+        if (!(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 1e-30 && rnorm2 < 1e30)) { give_up(d); return; }
+        {
+            // the window elements build_r16 wants in registers, from the LDS copy on every level (carried from the
+            // prologue in registers they lived in scratch across the level loop)
+            const float inv = (float)(1.0 / sqrt(rnorm2));
             int tq = threadIdx.x;
             asm volatile("" : "+v"(tq));
+            double win[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = tq + WG * u;
-                first[u] = i < N ? r64[i] : 0.0;
+                win[u] = i < N ? r64[i] : 0.0;
             }
+            build_r16(r64, N, inv, win, r16);
         }
-        // NaN / Inf / extreme scales: fp32
-        if (!(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 1e-30 && rnorm2 < 1e30)) { give_up(d); return; }
-        build_r16(r64, N, (float)(1.0 / sqrt(rnorm2)), first, r16);
         if (tid == 0) {
             sl->cand_cnt = 0;
             if (COLS) { cl->raw_cnt = 0; cl->gkey = fkey(-INFINITY); } else ll->gkey = fkey(-INFINITY);
@@ -1977,11 +1979,11 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
         } else {
             // ---- ONE sweep: a group's candidates are taken while it is in registers, against the node's running maximum
             // (the groups before, and this wave's own share of this one: a lower bound of the final maximum, so the
-            // entries kept are a superset), value beside index; the final band filters them behind the sweep.  Narrow
+            // entries kept are a superset), a bound of the value beside the index; the final band filters them behind the sweep.  Narrow
             // atoms first: their group holds the maximum most often (2 of 3 nodes on config 2), which keeps the early
             // thresholds tight.  Only when more than CAND_CAP entries pass the early thresholds is there a second sweep
             // with the final one (the round-1 scheme: every group in the band multiplied again)
-            auto collect = [&](int g, float thr, bool early) {
+            auto collect = [&](int g, float thr, bool early, float lbound) {
                 uint32_t mk[2] = {0u, 0u};
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
@@ -2002,16 +2004,11 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
                         const int idx = (prow + 16 * (r >> 2) + (r & 3)) * K + sl->perm[16 * (NG * g + nj) + lr];
                         const int slot = atomicAdd(&sl->cand_cnt, 1);
                         if (early) {
-                            float v = 0.f;
-#pragma unroll
-                            for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                                for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-                                    for (int n2 = 0; n2 < NG; ++n2) v = (e == (4 * mi + rg) * NG + n2) ? acc[mi][n2][rg] : v;
+                            // beside the index goes the LANE's maximum, an upper bound of the entry: the final filter then
+                            // keeps a few entries too many (re-scored in float64 like the rest) and never one too few
                             if (slot < CAND_CAP) {
                                 sl->cand_idx[slot] = idx;
-                                reinterpret_cast<float*>(sl->cand_val)[slot] = v;
+                                reinterpret_cast<float*>(sl->cand_val)[slot] = lbound;
                             }
                         } else {
                             // candidates 128 .. 255 wait in the space of the float64 scores, which nobody has written yet
@@ -2034,7 +2031,7 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
                     cur = old > mine ? old : mine;
                 }
                 const float tauw = fkey_inv((unsigned)__builtin_amdgcn_readlane((int)cur, 63)) - band;
-                if (lmax >= tauw) collect(g, tauw, true);
+                if (lmax >= tauw) collect(g, tauw, true, lmax);
             }
             __syncthreads();
             float gmax[NT / NG];
@@ -2066,28 +2063,16 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
                 __syncthreads();
                 if (keep >= 0) sl->cand_idx[atomicAdd(&sl->cand_cnt, 1)] = keep;
             } else {
-                // ---- sweep 2: candidates from the groups that reach the band; the last group is still in registers
+                // ---- sweep 2 (rare): the groups that reach the band are multiplied again, candidates by the final band
                 __syncthreads();                                          // (everybody has read nraw)
                 if (tq == 0) sl->cand_cnt = 0;
                 __syncthreads();
-                for (int gi = 0; gi < NT / NG; ++gi) {
-                    const int g = gi == 0 ? NT / NG - 1 : gi - 1;
+                for (int g = 0; g < NT / NG; ++g) {
                     if (!(gmax[g] >= tau)) continue;                      // uniform
                     bool lane_supp;
-                    float lmax;
-                    if (gi != 0) {
-                        gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
-                        lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, 0, permv, acc, lane_supp);
-                    } else {
-                        lmax = -INFINITY;
-#pragma unroll
-                        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                            for (int nj = 0; nj < NG; ++nj)
-#pragma unroll
-                                for (int rg = 0; rg < 4; ++rg) lmax = fmaxf(lmax, acc[mi][nj][rg]);
-                    }
-                    if (lmax >= tau) collect(g, tau, false);
+                    gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
+                    const float lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, 0, permv, acc, lane_supp);
+                    if (lmax >= tau) collect(g, tau, false, lmax);
                 }
             }
         }

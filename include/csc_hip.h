@@ -117,7 +117,8 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
  *               returns, src/csc/dictionary.py:1147-1148)
  *   d_stats     [4] int32 or NULL (must be zeroed by the caller): [0] selections that fell back
  *               to the fp32 arg-max (candidate overflow), [1] re-selected activations (dead Cholesky
- *               columns), [2] number of fp64 re-scored candidates, [3] nodes the fp16 filter could not
+ *               columns), [2] number of fp64 re-scored candidates (a diagnostic: it may vary by a few per
+ *               thousand from run to run, the outputs do not), [3] nodes the fp16 filter could not
  *               settle (multiplied again in fp32; on the single-child levels the rest of the node's chain is
  *               then done in fp32 too)
  *   workspace   csc_mmpdf_workspace_bytes(...) bytes, 16-byte aligned (hipMalloc's are): two generations of node

@@ -55,7 +55,14 @@ def test_static_scratch_entry_equals_workspace_entry(golden_signals):
             if calls > 1:                                          # (the first call may page the library's image in)
                 assert after[1] >= before[1] - (1 << 20), "device memory was allocated by the call"
             for n in NAMES:
-                assert torch.equal(mine[n], ref[n]), (n, c, B, K, S)
+                # stats[2], the number of re-scored candidates, is a diagnostic: a group's candidates are taken against
+                # the maximum the other waves have PUBLISHED so far, so a few entries more or fewer are re-scored from
+                # run to run (never one too few); everything that reaches an output is bit-identical
+                if n == "stats":
+                    assert torch.equal(mine[n][[0, 1, 3]], ref[n][[0, 1, 3]]), (n, c, B, K, S)
+                    assert abs(int(mine[n][2]) - int(ref[n][2])) <= max(64, int(ref[n][2]) // 50), (n, c, B, K, S)
+                else:
+                    assert torch.equal(mine[n], ref[n]), (n, c, B, K, S)
     # sizes beyond the static array are refused with a clear error, nothing is launched
     S_big = 4000
     sig = torch.zeros((S_big, 738), dtype=torch.float64, device=dev)
