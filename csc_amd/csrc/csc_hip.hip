@@ -1513,6 +1513,12 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_followup_kernel(const LevelAr
 // registers, LDS for four nodes per CU.  Everything behind the candidates is the shared code.
 // A node the fp16 filter cannot settle is flagged (a.flags) and left to mmp_level_followup_kernel (fp32), launched behind.
 #define NG 3
+// 1: the group loop stages its bank blocks L2 -> registers -> LDS instead of by LDS-DMA (so that the LDS-counter wait in
+// front of each barrier does not wait for copies in flight).  Measured equal (chain kernel 1.006 against 0.97 - 1.04 ms, a
+// lone sweep 24.6 k clocks either way): the product of a lone workgroup is not held up by that wait.  Kept for the record.
+#ifndef GROUP_STAGE_REGS
+#define GROUP_STAGE_REGS 0
+#endif
 #define GBLK (NG * BLKF)               // halves of one group-slab in the ring
 #define LRING 5                        // group-slabs in the ring: two being read, three copies ahead
 
@@ -1534,10 +1540,33 @@ __device__ __forceinline__ void gemm16_group(const _Float16* __restrict__ tile, 
 #pragma unroll
         for (int nj = 0; nj < NG; ++nj) acc[mi][nj] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const _Float16* ra = r16 + (lr & 7) * R16_CS + 64 * wave + (lr & 8) + 8 * lq;
+#if GROUP_STAGE_REGS
+    // The group's blocks go L2 -> registers -> LDS (waves 0..2: one block of each slab), NOT by LDS-DMA: a wave's
+    // LDS-DMA copies in flight count in its LDS counter, so the lgkmcnt(0) in front of every barrier waited for the
+    // copies of the slabs ahead as well and the ring's depth bought nothing (profiles/r02_stream_probe.json).  A pair of
+    // slabs is loaded while the pair before the one before is multiplied, written to the ring a pair later, read the
+    // pair after that: one barrier per pair as before, a ring of four slabs.
+    const bool copier = wave < NG;
+    const _Float16* src = tile + (NG * g + (copier ? wave : 0)) * BLKF + lane * 8;
+    _Float16* dstl = ring + (copier ? wave : 0) * BLKF + lane * 8;
+    f16x8 st0 = {}, st1 = {};
+    auto load_pair = [&](int s) {                                    // slabs s, s + 1 -> staging registers
+        if (copier && s < s1) st0 = *reinterpret_cast<const f16x8*>(src + (size_t)s * SLABF);
+        if (copier && s + 1 < s1) st1 = *reinterpret_cast<const f16x8*>(src + (size_t)(s + 1) * SLABF);
+    };
+    auto write_pair = [&](int s) {                                   // staging registers -> ring slots of slabs s, s + 1
+        if (copier && s < s1) *reinterpret_cast<f16x8*>(dstl + ((s - s0) & 3) * GBLK) = st0;
+        if (copier && s + 1 < s1) *reinterpret_cast<f16x8*>(dstl + ((s + 1 - s0) & 3) * GBLK) = st1;
+    };
+    load_pair(s0);
+    write_pair(s0);
+    load_pair(s0 + 2);
+#else
     WAIT_VM(0);                                                      // nothing of ours in flight: the counts below hold
 #pragma unroll
     for (int q = 0; q < 3; ++q)
         if (s0 + q < s1) stage_group16(tile + (size_t)(s0 + q) * SLABF, ring + q * GBLK, g, wave, lane);
+#endif
     // A fragment (mi + 2, s) is fragment (mi, s + 1) (32 window elements further either way): two of the four
     // fragments of a slab are carried over from the slab before; the other two are requested one slab ahead, into
     // the registers of the pair that has just been used for the last time (X and Y swap roles every slab)
@@ -1573,6 +1602,18 @@ __device__ __forceinline__ void gemm16_group(const _Float16* __restrict__ tile, 
     };
     // Two slabs per barrier: at the top of a pair slabs s and s + 1 have landed (slab s + 2 may be in flight),
     // and the two ring slots of the pair before are free for the copies of slabs s + 3 and s + 4.
+#if GROUP_STAGE_REGS
+    for (int s = s0; s < s1; s += 2) {
+        __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));   // lgkmcnt(0): reads and writes done
+        __builtin_amdgcn_s_barrier();
+        // the pair staged a pair ago goes to the slots the pair before this one has left; the pair after it is requested
+        write_pair(s + 2);
+        load_pair(s + 4);
+        const int slot = (s - s0) & 3, sl1 = (s + 1 - s0) & 3;
+        slab(s, slot, std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{}, sl1);
+        if (s + 1 < s1) slab(s + 1, sl1, std::integral_constant<int, 2>{}, std::false_type{}, std::false_type{}, 0);
+    }
+#else
     int slot = 0;
     for (int s = s0; s < s1; s += 2) {
         if (s + 2 < s1) WAIT_VM(1); else WAIT_VM(0);                 // one copy per slab and wave (waves 0..2)
@@ -1587,6 +1628,7 @@ __device__ __forceinline__ void gemm16_group(const _Float16* __restrict__ tile, 
         if (s + 1 < s1) slab(s + 1, sl1, std::integral_constant<int, 2>{}, std::false_type{}, std::false_type{}, 0);
         slot = sl1 + 1 >= LRING ? sl1 + 1 - LRING : sl1 + 1;
     }
+#endif
     __syncthreads();
 }
 
