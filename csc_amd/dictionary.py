@@ -727,12 +727,15 @@ class CSCDictionary:
         """json.dump(dict(header, **{list_key: [sparVar entries]}), indent=4, default=handle_non_serializable) --
         the SAME BYTES (reference :1148-1150) -- with the list written by the library's streaming writer straight
         from the packed records (csc_sparvar_json_write, include/csc_hip.h) instead of through ~30 Python objects
-        per signal.  Returns False (nothing written) when an id / snr is not a plain int / float, so that the
-        caller can fall back to json.dump."""
+        per signal.  Returns False (nothing written) when an id / snr is not a plain int / float, or an atom
+        parameter is not a float (json.dump writes an int parameter as `1`, the writer formats doubles: `1.0`),
+        so that the caller can fall back to json.dump."""
         import ctypes as C
         from . import _lib
         if not all(type(i) is int for i in ids) or not all(type(v) in (int, float) for v in snrs):
             return False
+        if not all(isinstance(a.params[k], float) for a in self.atoms for k in ("b", "y", "sigma")):
+            return False                           # (np.float64 is a float; a Python / NumPy int is not)
         if any(abs(i) >= 2 ** 63 for i in ids) or any(type(v) is int and abs(v) >= 2 ** 53 for v in snrs):
             return False
         S, K = len(res), res.max_sparsity

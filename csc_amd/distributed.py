@@ -22,7 +22,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-_device_checked = False
+_device_checked = None      # the default process group the one-rank-per-GPU check last passed for
 
 
 def is_distributed() -> bool:
@@ -39,7 +39,8 @@ def world_size() -> int:
 
 def local_device():
     """The GPU of this process (None without one).  Under an initialised multi-rank process group the
-    choice is made HERE, not left to the caller: cuda:LOCAL_RANK, made current for the process."""
+    choice is made HERE, not left to the caller: cuda:LOCAL_RANK, made current for the process (a side
+    effect on purpose: ``torch.cuda.set_device`` -- every later allocation of the process lands there)."""
     if not torch.cuda.is_available():
         return None
     if is_distributed() and world_size() > 1:
@@ -59,7 +60,11 @@ def _check_one_rank_per_device(dev):
     """Once per process group: fail loudly if two ranks on one host use the same GPU (RCCL would hang or
     refuse later, with a less readable message)."""
     global _device_checked
-    if _device_checked or not is_distributed() or world_size() == 1 or dev is None or dev.type != "cuda":
+    if not is_distributed():
+        _device_checked = None                    # a process group initialised later is checked again
+        return
+    group = dist.distributed_c10d._get_default_group()
+    if _device_checked is group or world_size() == 1 or dev is None or dev.type != "cuda":
         return
     mine = (socket.gethostname(), int(dev.index if dev.index is not None else torch.cuda.current_device()))
     seen = [None] * world_size()
@@ -67,7 +72,7 @@ def _check_one_rank_per_device(dev):
     if len(set(seen)) != len(seen):
         raise RuntimeError(f"csc_amd: two ranks share a GPU {sorted(seen)}; run one process per GPU "
                            "(torchrun --nproc-per-node N sets LOCAL_RANK, which csc_amd follows)")
-    _device_checked = True
+    _device_checked = group
 
 
 def shard_range(n: int, r: int, world: int):
@@ -86,7 +91,8 @@ def gather_rows(local: torch.Tensor, sizes, dst: int = 0, out=None):
     this rank's GPU (nccl) or on the host (gloo).  Returns the [sum(sizes), width] tensor on rank ``dst`` (same
     device kind), None elsewhere.  Shards are padded to the largest so that one equal-size ``dist.gather``
     does it; ``out`` (rank dst: a list of world [cap, width] buffers) lets a caller reuse the receive
-    buffers from call to call."""
+    buffers from call to call -- the result is then assembled from those buffers and, with one rank, IS
+    ``out[0]`` (no copy): the next call with the same ``out`` overwrites it, so consume or clone it first."""
     assert local.dtype == torch.uint8 and local.dim() == 2
     if not is_distributed():
         assert local.shape[0] == sum(sizes)

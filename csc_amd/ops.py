@@ -31,12 +31,32 @@ def _tree_nodes(max_sparsity, connections, branches):
     return _lib.tree_shape(max_sparsity, connections, branches)[1]
 
 
+def _require(t, name, dtype, ndim, device=None, numel=None):
+    """The C ABI takes raw pointers: a tensor of the wrong dtype, device or layout would be read as something
+    else (a float32 ``signals`` as [S][N] float64 runs past its allocation), so the ops refuse it here."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} dimension(s), got shape {tuple(t.shape)}")
+    if t.device.type != "cuda":
+        raise ValueError(f"{name}: expected a CUDA (ROCm) tensor, got device {t.device}")
+    if device is not None and t.device != device:
+        raise ValueError(f"{name}: on {t.device}, but the signals are on {device}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if numel is not None and t.numel() != numel:
+        raise ValueError(f"{name}: expected {numel} elements, got {t.numel()}")
+
+
 @torch.library.custom_op("csc_amd::bank_pack", mutates_args=(), device_types="cuda")
 def bank_pack(bank64: torch.Tensor) -> torch.Tensor:
     """[K, L] float64 atom bank -> the packed matrix-core image (csc_bank_pack)."""
     lib = _lib.lib()
+    _require(bank64, "bank64", torch.float64, 2)
     K, L = bank64.shape
-    b = bank64.contiguous()
+    b = bank64
     out = torch.empty(lib.csc_bank32_elems(K, L), dtype=torch.float32, device=b.device)
     with torch.cuda.device(b.device):
         _lib.check(lib.csc_bank_pack(_ptr(b), K, L, _ptr(out),
@@ -54,11 +74,12 @@ def _(bank64):
 def similarity_table(bank64: torch.Tensor, signal_length: int, threshold: float) -> torch.Tensor:
     """Atom-vs-atom similarity bit table for signals of length N (csc_similarity_table)."""
     lib = _lib.lib()
+    _require(bank64, "bank64", torch.float64, 2)
     K, L = bank64.shape
     W = lib.csc_sim_words(signal_length, L)
     if W <= 0:
         raise ValueError(f"signal length {signal_length} shorter than atom length {L}")
-    b = bank64.contiguous()
+    b = bank64
     out = torch.empty(K * K * W, dtype=torch.int32, device=b.device)
     with torch.cuda.device(b.device):
         _lib.check(lib.csc_similarity_table(_ptr(b), K, L, signal_length, float(threshold), _ptr(out),
@@ -80,10 +101,19 @@ def mmpdf_batch(bank32t: torch.Tensor, bank64: torch.Tensor, sim_bits: Optional[
     """Batched MMP-DF / OMP on [S, N] float64 signals (csc_mmpdf_batch) -> (node_pos [S, NN] i32,
     node_atom [S, NN] i32, node_mse [S, NN] f64, records [S, (16 + 8 K) K] u8)."""
     lib = _lib.lib()
-    K, L = bank64.shape
-    sig = signals.contiguous()
+    if isinstance(signals, torch.Tensor) and signals.dim() == 2 and not signals.is_contiguous():
+        signals = signals.contiguous()
+    _require(signals, "signals", torch.float64, 2)
+    sig = signals
     S, N = sig.shape
     dev = sig.device
+    _require(bank64, "bank64", torch.float64, 2, dev)
+    K, L = bank64.shape
+    _require(bank32t, "bank32t", torch.float32, 1, dev, lib.csc_bank32_elems(K, L))
+    if N < L:
+        raise ValueError(f"signal length {N} shorter than atom length {L}")
+    if sim_bits is not None:
+        _require(sim_bits, "sim_bits", torch.int32, 1, dev, K * K * lib.csc_sim_words(N, L))
     NN = _tree_nodes(max_sparsity, connections, branches)
     Kx = max_sparsity
     with torch.cuda.device(dev):

@@ -614,6 +614,30 @@ def test_torch_custom_ops_match_the_engine(golden_signals):
     # OMP through the op: no similarity table
     pos1, _, _, _ = torch.ops.csc_amd.mmpdf_batch(b32, b64, None, sig, 3, 1, 1, 0)
     assert torch.equal(pos1[:, 0], pos[:, 0])
+    # the ops hand raw pointers to the C ABI: wrong dtype / size / device / layout must raise, not be re-interpreted
+    with pytest.raises(TypeError):
+        torch.ops.csc_amd.mmpdf_batch(b32, b64, sim, sig.float(), 5, 3, 3, 0)
+    with pytest.raises(TypeError):
+        torch.ops.csc_amd.mmpdf_batch(b32.double(), b64, sim, sig, 5, 3, 3, 0)
+    with pytest.raises(TypeError):
+        torch.ops.csc_amd.mmpdf_batch(b32, b64.float(), sim, sig, 5, 3, 3, 0)
+    with pytest.raises(TypeError):
+        torch.ops.csc_amd.mmpdf_batch(b32, b64, sim.long(), sig, 5, 3, 3, 0)
+    with pytest.raises(ValueError):
+        torch.ops.csc_amd.mmpdf_batch(b32[:-4], b64, sim, sig, 5, 3, 3, 0)
+    with pytest.raises(ValueError):
+        torch.ops.csc_amd.mmpdf_batch(b32, b64, sim[:-1], sig, 5, 3, 3, 0)
+    with pytest.raises(ValueError):
+        torch.ops.csc_amd.mmpdf_batch(b32, b64, sim, sig[:, :400], 5, 3, 3, 0)          # shorter than an atom
+    with pytest.raises(TypeError):
+        torch.ops.csc_amd.bank_pack(b64.float())
+    with pytest.raises(ValueError):
+        torch.ops.csc_amd.bank_pack(b64.t())                                            # not contiguous
+    # a non-contiguous view of the signals is copied, not refused
+    wide = torch.zeros((24, 800), dtype=torch.float64, device=bank.device)
+    wide[:, :738] = sig
+    pos2, _, _, rec2 = torch.ops.csc_amd.mmpdf_batch(b32, b64, sim, wide[:, :738], 5, 3, 3, 0)
+    assert torch.equal(pos2, pos) and torch.equal(rec2, rec)
 
 
 

@@ -271,6 +271,14 @@ def test_streaming_writer_is_byte_identical_to_json_dump(dic, golden_signals, tm
         assert open(a, "rb").read() == open(b, "rb").read(), n
     # ids / snr values the fast writer does not take are left to json.dump
     assert not dic._dump_sparvar_stream(header, "mmp", res, ["a"] * 5, snrs, 0.1, str(tmp_path / "c.json"))
+    # so is a dictionary with an integer atom parameter (json.dump writes `1`, a double formatter `1.0`)
+    saved = dic.atoms[0].params["b"]
+    try:
+        dic.atoms[0].params["b"] = 1
+        assert not dic._dump_sparvar_stream(header, "mmp", res, ids, snrs, 0.1, str(tmp_path / "c.json"))
+    finally:
+        dic.atoms[0].params["b"] = saved
+    assert dic._dump_sparvar_stream(header, "mmp", res, ids, snrs, 0.1, str(tmp_path / "c.json"))
     # float formatting alone, against Python's repr
     import ctypes as C
     from csc_amd import _lib
