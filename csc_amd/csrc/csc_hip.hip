@@ -1503,193 +1503,43 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_followup_kernel(const LevelAr
     }
 }
 
-// ---- the lean level kernel: the same node, three column groups at a time ----------------------------------
+// ---- the chain kernel: single-child levels, wave-private product ------------------------------------------------
 // mmp_level_kernel keeps the whole (256 x 144) correlation matrix in registers, 144 VGPRs per lane, which allows
 // two nodes per CU -- and a node is a chain of short dependent steps, so the CU idles.  A node does not need the
-// matrix at once: only its maximum and the few entries within the band of it.  Here the fp16 product is taken in
-// three groups of NG = 3 column tiles (48 atoms, 48 accumulator VGPRs, 3 KB of bank per slab): sweep 1 keeps each
-// group's maximum (after suppression by the earlier siblings, read from the similarity table), sweep 2 collects
-// the candidates from the groups that reach the band, recomputing them -- 4/3 of the MFMA work, a third of the
-// registers, LDS for four nodes per CU.  Everything behind the candidates is the shared code.
+// matrix at once: only its maximum and the few entries within the band of it.  Here the fp16 product is cut into
+// TASKS of (128 positions x 16 bank columns), each owned by ONE wave from its first slab to its last: 32 accumulator
+// VGPRs, no barrier and no LDS traffic for the bank at all --
+//   B fragments   the bank's fp16 blocks are stored fragment-major (one 16-byte piece per lane), so a wave's B fragment
+//                 of (slab, column tile) is ONE global_load_dwordx4 straight from L2 into registers, requested BD = 5
+//                 slabs ahead (a ring of five registers, counted vmcnt waits);
+//   A fragments   the Hankel windows of the residual, from the eight shifted fp16 copies in LDS: a task's slab uses
+//                 window fragments u = 2 s .. 2 s + 7 (row tile mi, slab s -> u = mi + 2 s), ten registers in rotation,
+//                 two new 16-byte LDS reads per slab;
+//   per slab      8 MFMAs (v_mfma_f32_16x16x32_f16) on one B fragment.
+// A column tile is multiplied only over ITS live slab range (the bank's columns are sorted by support; outside the
+// range the tile's blocks are zero padding): 101 of 144 (slab, tile) blocks on the canonical bank, where the
+// three-group loop this replaces multiplied 111.  The 18 tasks of a node are dealt to the four waves longest first.
+// A finished task is complete in registers, so its candidates are taken at once against the node's RUNNING maximum (the
+// tasks finished before, by an LDS atomicMax, and this task's own maximum: a lower bound of the final maximum, so the
+// entries kept are a superset), value beside index; the final band filters them behind the product's one barrier.
+// The next task's first B fragments and its window are requested BEFORE the finished task's epilogue.
+// (scripts/probe/prod_probe.hip times this loop against the three-group loop: 0.74 against 0.86 ms per 40 960 node
+// products, matrix pipe 98 % full at four workgroups per CU, where the chip holds 1.45 GHz.)
 // A node the fp16 filter cannot settle is flagged (a.flags) and left to mmp_level_followup_kernel (fp32), launched behind.
-#define NG 3
-// 1: the group loop stages its bank blocks L2 -> registers -> LDS instead of by LDS-DMA (so that the LDS-counter wait in
-// front of each barrier does not wait for copies in flight).  Measured equal (chain kernel 1.006 against 0.97 - 1.04 ms, a
-// lone sweep 24.6 k clocks either way): the product of a lone workgroup is not held up by that wait.  Kept for the record.
-#ifndef GROUP_STAGE_REGS
-#define GROUP_STAGE_REGS 0
-#endif
-#define GBLK (NG * BLKF)               // halves of one group-slab in the ring
-#define LRING 5                        // group-slabs in the ring: two being read, three copies ahead
+#define NG 3                           // (column tiles per group of the large-dictionary kernels below)
+#define BD 5                           // B fragments in flight per wave
+#define RAW_CAP 512
+#define TASK_SLOTS 16                  // descriptors per wave: slots 0 .. 14 tasks, slot 15 their number
+struct ChainLds {
+    unsigned desc[WG / 64][TASK_SLOTS];   // task = column tile | row half << 4 | first live slab << 8 | one past the last << 16
+    unsigned short range[NT + 1];      // per column tile: first live slab | one past the last << 8
+    unsigned gkey;                     // running maximum of the node's filter product (fkey)
+    int raw_cnt;
+    int raw_idx[RAW_CAP];
+    float raw_val[RAW_CAP];
+};
 
-// group-slab s of group g: blocks 3g .. 3g + 2 of slab s, one 1 KiB copy per wave 0..2
-__device__ __forceinline__ void stage_group16(const _Float16* gslab, _Float16* lslab, int g, int wave, int lane) {
-    if (wave < NG)
-        __builtin_amdgcn_global_load_lds((gptr_t)(gslab + (NG * g + wave) * BLKF + lane * 8),
-                                         (lptr_t)(lslab + wave * BLKF), 16, 0, 0);
-}
-
-// acc[mi][nj] = correlations of positions 64 wave + 16 mi + ..., column tile 3 g + nj, over slabs [s0, s1)
-__device__ __forceinline__ void gemm16_group(const _Float16* __restrict__ tile, int g, int s0, int s1,
-                                             const _Float16* r16, _Float16* ring, f32x4 (&acc)[MT][NG]) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 15, lq = lane >> 4;
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-        for (int nj = 0; nj < NG; ++nj) acc[mi][nj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const _Float16* ra = r16 + (lr & 7) * R16_CS + 64 * wave + (lr & 8) + 8 * lq;
-#if GROUP_STAGE_REGS
-    // The group's blocks go L2 -> registers -> LDS (waves 0..2: one block of each slab), NOT by LDS-DMA: a wave's
-    // LDS-DMA copies in flight count in its LDS counter, so the lgkmcnt(0) in front of every barrier waited for the
-    // copies of the slabs ahead as well and the ring's depth bought nothing (profiles/r02_stream_probe.json).  A pair of
-    // slabs is loaded while the pair before the one before is multiplied, written to the ring a pair later, read the
-    // pair after that: one barrier per pair as before, a ring of four slabs.
-    const bool copier = wave < NG;
-    const _Float16* src = tile + (NG * g + (copier ? wave : 0)) * BLKF + lane * 8;
-    _Float16* dstl = ring + (copier ? wave : 0) * BLKF + lane * 8;
-    f16x8 st0 = {}, st1 = {};
-    auto load_pair = [&](int s) {                                    // slabs s, s + 1 -> staging registers
-        if (copier && s < s1) st0 = *reinterpret_cast<const f16x8*>(src + (size_t)s * SLABF);
-        if (copier && s + 1 < s1) st1 = *reinterpret_cast<const f16x8*>(src + (size_t)(s + 1) * SLABF);
-    };
-    auto write_pair = [&](int s) {                                   // staging registers -> ring slots of slabs s, s + 1
-        if (copier && s < s1) *reinterpret_cast<f16x8*>(dstl + ((s - s0) & 3) * GBLK) = st0;
-        if (copier && s + 1 < s1) *reinterpret_cast<f16x8*>(dstl + ((s + 1 - s0) & 3) * GBLK) = st1;
-    };
-    load_pair(s0);
-    write_pair(s0);
-    load_pair(s0 + 2);
-#else
-    WAIT_VM(0);                                                      // nothing of ours in flight: the counts below hold
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-        if (s0 + q < s1) stage_group16(tile + (size_t)(s0 + q) * SLABF, ring + q * GBLK, g, wave, lane);
-#endif
-    // A fragment (mi + 2, s) is fragment (mi, s + 1) (32 window elements further either way): two of the four
-    // fragments of a slab are carried over from the slab before; the other two are requested one slab ahead, into
-    // the registers of the pair that has just been used for the last time (X and Y swap roles every slab)
-    f16x8 af[MT];
-    af[0] = *reinterpret_cast<const f16x8*>(ra + 32 * s0);
-    af[1] = *reinterpret_cast<const f16x8*>(ra + 32 * s0 + 16);
-    af[2] = *reinterpret_cast<const f16x8*>(ra + 32 * s0 + 32);
-    af[3] = *reinterpret_cast<const f16x8*>(ra + 32 * s0 + 48);
-#define LEAN_MFMA(A, B, mi, nj) acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc[mi][nj], 0, 0, 0)
-    // X = af[x0], af[x0 + 1] hold row tiles 0, 1 of slab s, Y = the other two hold row tiles 2, 3
-    // `first`: the slab's B fragments are read here (first slab behind a barrier); `pref`: the B fragments
-    // of the pair's second slab (ring slot `next`) are requested behind the last use of this slab's
-    f16x8 bf[NG];
-    auto slab = [&](int s, int slot, auto xc, auto firstc, auto prefc, int next) {
-        constexpr int x0 = decltype(xc)::value, y0 = 2 - x0;
-        constexpr bool first = decltype(firstc)::value, pref = decltype(prefc)::value;
-        const _Float16* sb = ring + slot * GBLK + lane * 8;
-        if (first) {
-#pragma unroll
-            for (int nj = 0; nj < NG; ++nj) bf[nj] = *reinterpret_cast<const f16x8*>(sb + nj * BLKF);
-        }
-#pragma unroll
-        for (int nj = 0; nj < NG; ++nj) { LEAN_MFMA(af[x0], bf[nj], 0, nj); LEAN_MFMA(af[x0 + 1], bf[nj], 1, nj); }
-        af[x0] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 64);          // row tiles 2, 3 of slab s + 1
-        af[x0 + 1] = *reinterpret_cast<const f16x8*>(ra + 32 * s + 80);      // (inside the copy for s + 1 = 16 too)
-        const _Float16* sn = ring + next * GBLK + lane * 8;
-#pragma unroll
-        for (int nj = 0; nj < NG; ++nj) {
-            LEAN_MFMA(af[y0], bf[nj], 2, nj);
-            LEAN_MFMA(af[y0 + 1], bf[nj], 3, nj);
-            if (pref) bf[nj] = *reinterpret_cast<const f16x8*>(sn + nj * BLKF);
-        }
-    };
-    // Two slabs per barrier: at the top of a pair slabs s and s + 1 have landed (slab s + 2 may be in flight),
-    // and the two ring slots of the pair before are free for the copies of slabs s + 3 and s + 4.
-#if GROUP_STAGE_REGS
-    for (int s = s0; s < s1; s += 2) {
-        __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));   // lgkmcnt(0): reads and writes done
-        __builtin_amdgcn_s_barrier();
-        // the pair staged a pair ago goes to the slots the pair before this one has left; the pair after it is requested
-        write_pair(s + 2);
-        load_pair(s + 4);
-        const int slot = (s - s0) & 3, sl1 = (s + 1 - s0) & 3;
-        slab(s, slot, std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{}, sl1);
-        if (s + 1 < s1) slab(s + 1, sl1, std::integral_constant<int, 2>{}, std::false_type{}, std::false_type{}, 0);
-    }
-#else
-    int slot = 0;
-    for (int s = s0; s < s1; s += 2) {
-        if (s + 2 < s1) WAIT_VM(1); else WAIT_VM(0);                 // one copy per slab and wave (waves 0..2)
-        __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));   // lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        const int sl3 = slot + 3 >= LRING ? slot + 3 - LRING : slot + 3, sl4 = sl3 + 1 >= LRING ? sl3 + 1 - LRING : sl3 + 1;
-        if (s + 3 < s1) stage_group16(tile + (size_t)(s + 3) * SLABF, ring + sl3 * GBLK, g, wave, lane);
-        if (s + 4 < s1) stage_group16(tile + (size_t)(s + 4) * SLABF, ring + sl4 * GBLK, g, wave, lane);
-        const int sl1 = slot + 1 >= LRING ? slot + 1 - LRING : slot + 1;
-        // (at an odd end the request for the missing second slab reads a ring slot nobody waits for: unused)
-        slab(s, slot, std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{}, sl1);
-        if (s + 1 < s1) slab(s + 1, sl1, std::integral_constant<int, 2>{}, std::false_type{}, std::false_type{}, 0);
-        slot = sl1 + 1 >= LRING ? sl1 + 1 - LRING : sl1 + 1;
-    }
-#endif
-    __syncthreads();
-}
-
-// masking of the entries outside the matrix + suppression by the first t siblings (bits from the similarity
-// table in L2); returns the lane's maximum over its unsuppressed entries, lane_supp = it holds a suppressed one
-__device__ __forceinline__ float group_finish(const LevelArgs& a, const NodeLds* sl, const int* sib_pos,
-                                              const int* sib_atom, int g, int t, int (&permv)[NG],
-                                              f32x4 (&acc)[MT][NG], bool& lane_supp) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lr = lane & 15, lq = lane >> 4;
-    const int K = a.K, P = a.P, W = a.W;
-    const int prow = 64 * wave + 4 * lq;
-#pragma unroll
-    for (int nj = 0; nj < NG; ++nj) permv[nj] = sl->perm[16 * (NG * g + nj) + lr];
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-        if (64 * wave + 16 * mi + 15 >= P) {                         // wave-uniform
-#pragma unroll
-            for (int nj = 0; nj < NG; ++nj)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg)
-                    if (prow + 16 * mi + rg >= P) acc[mi][nj][rg] = -INFINITY;
-        }
-#pragma unroll
-    for (int nj = 0; nj < NG; ++nj)
-        if (permv[nj] < 0) {
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) acc[mi][nj] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        }
-    lane_supp = false;
-    for (int q = 0; q < t; ++q) {
-        const int dpb = prow - sib_pos[q] + P - 1;                   // bit index of (mi, rg) = (0, 0); >= 0
-        const int w0 = dpb >> 5, b0 = dpb & 31;
-        const uint32_t* srow = a.sim_bits + (size_t)sib_atom[q] * K * W;
-#pragma unroll
-        for (int nj = 0; nj < NG; ++nj) {
-            const uint32_t* row = srow + (size_t)max(permv[nj], 0) * W;
-            const uint32_t wd0 = row[min(w0, W - 1)], wd1 = row[min(w0 + 1, W - 1)], wd2 = row[min(w0 + 2, W - 1)];
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int off = b0 + 16 * mi + rg;               // < 32 + 52
-                    const uint32_t wd = off < 32 ? wd0 : (off < 64 ? wd1 : wd2);
-                    const bool hit = ((wd >> (off & 31)) & 1u) && acc[mi][nj][rg] > -INFINITY;
-                    acc[mi][nj][rg] = hit ? __uint_as_float(SUPP_BITS) : acc[mi][nj][rg];
-                    lane_supp |= hit;
-                }
-        }
-    }
-    float lmax = -INFINITY;
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-        for (int nj = 0; nj < NG; ++nj)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) lmax = fmaxf(lmax, acc[mi][nj][rg]);
-    return lmax;
-}
-
-// float <-> unsigned key with the same order (for LDS atomicMax on unit maxima)
+// float <-> unsigned key with the same order (for LDS atomicMax on maxima)
 __device__ __forceinline__ unsigned fkey(float f) {
     const unsigned b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
@@ -1697,179 +1547,211 @@ __device__ __forceinline__ unsigned fkey(float f) {
 __device__ __forceinline__ float fkey_inv(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
-
-// ---- the column-owner product of the chain kernel ---------------------------------------------------------------
-// A wave owns whole 16-column tiles of the bank against ALL 16 row tiles (P <= 256): one B fragment and two new A
-// fragments per 16 MFMAs (3 KB of LDS reads instead of the 5 KB per 12 MFMAs of the group loop above), no barrier
-// inside the product, every wave streaming its own tiles L2 -> LDS through a private ring (the pattern of the
-// large-dictionary screen, screen_blocks16).  The nine column tiles are dealt to the four waves longest first
-// (ColsLds::witem, by live slabs).  A finished tile is complete in registers, so its candidates are taken at once,
-// against the node's running maximum (an LDS atomicMax; a lower bound of the final maximum, so the entries kept are a
-// superset), value beside index; the chain filters them by the final band behind the product's one barrier: one
-// sweep, nothing multiplied twice.
-#define LEAN_AHEAD 6                   // ring slots (1 KiB blocks) per wave
-#define RAW_CAP 512
-struct ColsLds {
-    unsigned short crange[NT + 1];     // per column tile: first live slab | one past the last << 8
-    unsigned short order[NT + 1];      // column tiles by falling number of live slabs: tile | slabs << 8
-    unsigned char witem[WG / 64][NT + 3];   // per wave: number of tiles, then the tiles
-    unsigned gkey;                     // running maximum of the node's filter product (fkey)
-    int raw_cnt;
-    int raw_idx[RAW_CAP];
-    float raw_val[RAW_CAP];
-};
-
-__device__ __forceinline__ void lean_cols16(const LevelArgs& a, const NodeLds* sl, ColsLds* cl, const _Float16* r16,
-                                            _Float16* ring, float band) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lr = lane & 15, lq = lane >> 4;
-    const int P = a.P, K = a.K;
-    _Float16* myring = ring + wave * (LEAN_AHEAD * BLKF);
-    const unsigned char* items = cl->witem[wave];
-    const int nit = __builtin_amdgcn_readfirstlane((int)items[0]);
-    auto item_range = [&](int c, int& s0, int& s1) {
-        const int pk = __builtin_amdgcn_readfirstlane((int)cl->crange[c]);
-        s0 = pk & 0xff;
-        s1 = pk >> 8;
-    };
-    // the wave's stream of B blocks: the copy cursor runs LEAN_AHEAD slabs ahead of the multiplication, across tiles
-    int ci = 0, cs = 0, ce = 0, cslot = 0;
-    bool more = true;
-    const _Float16* cb = a.bank16;
-    auto cursor_copy = [&]() {
-        while (cs >= ce) {
-            if (!more) return;
-            if (ci >= nit) { more = false; return; }
-            const int c = __builtin_amdgcn_readfirstlane((int)items[1 + ci]);
-            ++ci;
-            item_range(c, cs, ce);
-            cb = a.bank16 + c * BLKF + lane * 8;
-        }
-        __builtin_amdgcn_global_load_lds((gptr_t)(cb + (size_t)cs * SLABF), (lptr_t)(myring + cslot * BLKF), 16, 0, 0);
-        ++cs;
-        cslot = cslot == LEAN_AHEAD - 1 ? 0 : cslot + 1;
-    };
-    WAIT_VM(0);
-#pragma unroll
-    for (int i = 0; i < LEAN_AHEAD; ++i) cursor_copy();
-    f16x8 W[20], b[2];
-    f32x4 acc[16];
-    int slot = 0;
-    if (more) WAIT_VM(LEAN_AHEAD - 1); else WAIT_VM(0);
-    b[0] = *reinterpret_cast<const f16x8*>(myring + lane * 8);
-    const _Float16* pa = r16 + (lr & 7) * R16_CS + (lr & 8) + 8 * lq;
-    // one slab: slab s of a tile that starts at s0 multiplies the window fragments 2 (s - s0) + 0 .. 15, kept in
-    // eighteen registers in rotation (the two of slab s + 1 that slab s does not use are read here)
-    auto body = [&](auto phc, auto firstc, int s) {
-        constexpr int PH = decltype(phc)::value;
-        constexpr bool FIRST = decltype(firstc)::value;
-        if (more) WAIT_VM(LEAN_AHEAD - 2); else WAIT_VM(0);
-        const int nslot = slot == LEAN_AHEAD - 1 ? 0 : slot + 1;
-        b[(PH + 1) & 1] = *reinterpret_cast<const f16x8*>(myring + nslot * BLKF + lane * 8);
-        W[(2 * PH + 16) % 20] = *reinterpret_cast<const f16x8*>(pa + 32 * s + 16 * 16);
-        W[(2 * PH + 17) % 20] = *reinterpret_cast<const f16x8*>(pa + 32 * s + 16 * 17);
-#pragma unroll
-        for (int mi = 0; mi < 16; ++mi)
-            acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[(2 * PH + mi) % 20], b[PH & 1],
-                                                             FIRST ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mi], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        cursor_copy();
-        slot = nslot;
-    };
-    for (int it = 0; it < nit; ++it) {
-        const int c = __builtin_amdgcn_readfirstlane((int)items[1 + it]);
-        int s0, s1;
-        item_range(c, s0, s1);
-        const int atom = sl->perm[16 * c + lr];
-        if (s0 >= s1) {
-            if (atom >= 0) atomicAdd(&cl->raw_cnt, RAW_CAP + 1);
-            continue;
-        }
-        {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) W[i] = *reinterpret_cast<const f16x8*>(pa + 32 * s0 + 16 * i);
-            int s = s0;
-#define COLS_STEP(PH) body(std::integral_constant<int, PH>{}, std::false_type{}, s); \
-            if (++s >= s1) { if (((PH) & 1) == 0) b[0] = b[1]; break; }
-            body(std::integral_constant<int, 0>{}, std::true_type{}, s);
-            if (++s >= s1) {
-                b[0] = b[1];
-            } else {
-                while (true) {
-                    COLS_STEP(1) COLS_STEP(2) COLS_STEP(3) COLS_STEP(4) COLS_STEP(5)
-                    COLS_STEP(6) COLS_STEP(7) COLS_STEP(8) COLS_STEP(9) COLS_STEP(0)
-                }
-            }
-#undef COLS_STEP
-        }
-        // the tile's 256 x 16 correlations are complete: rows >= P and padding columns out, maximum, candidates
-        float lmax = -INFINITY;
-#pragma unroll
-        for (int mi = 0; mi < 16; ++mi) {
-            if (16 * mi + 15 >= P) {                                 // (uniform)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg)
-                    if (16 * mi + 4 * lq + rg >= P) acc[mi][rg] = -INFINITY;
-            }
-            lmax = fmaxf(lmax, fmaxf(fmaxf(acc[mi][0], acc[mi][1]), fmaxf(acc[mi][2], acc[mi][3])));
-        }
-        if (atom < 0) lmax = -INFINITY;
-        float bm = wave_max(lmax);
-        bm = bm == bm ? bm : INFINITY;
-        unsigned cur = 0;
-        if (lane == 63) {
-            const unsigned mine = fkey(bm);
-            const unsigned old = atomicMax(&cl->gkey, mine);
-            cur = old > mine ? old : mine;
-        }
-        const float tauw = fkey_inv((unsigned)__builtin_amdgcn_readlane((int)cur, 63)) - band;
-        if (lmax >= tauw) {
-#pragma unroll
-            for (int mi = 0; mi < 16; ++mi) {
-                const f32x4 v4 = acc[mi];
-                uint32_t mm = (v4[0] >= tauw ? 1u : 0u) | (v4[1] >= tauw ? 2u : 0u) | (v4[2] >= tauw ? 4u : 0u) |
-                              (v4[3] >= tauw ? 8u : 0u);
-                while (mm) {
-                    const int rg = __builtin_ctz(mm);
-                    mm &= mm - 1;
-                    const float v = rg == 0 ? v4[0] : (rg == 1 ? v4[1] : (rg == 2 ? v4[2] : v4[3]));
-                    const int at = atomicAdd(&cl->raw_cnt, 1);
-                    if (at < RAW_CAP) {
-                        cl->raw_idx[at] = (16 * mi + 4 * lq + rg) * K + atom;
-                        cl->raw_val[at] = v;
-                    }
-                }
-            }
-        }
-    }
-    WAIT_VM(0);
+// v_max3_f32 as it stands (fmaxf through the compiler comes with a canonicalising v_max x, x per operand)
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
-struct LeanLds {
-    float wgmax[NT / NG][WG / 64];     // sweep 1: maximum of each group per wave
-    int sib_pos[1], sib_atom[1];       // (no siblings on the chain levels: group_finish is called with t = 0)
-    int s0[NT / NG], s1[NT / NG];      // slab range of each group (outside it the group's blocks are zero padding)
-    unsigned gkey;                     // running maximum of the node's filter product (fkey)
-};
+// The node's tasks, built by 9 + 18 threads: (1) thread c < 9: live slab range of column tile c from the bank's block
+// masks (global: no wait for the LDS copy); (2) behind a barrier, thread t < 18 = (tile, row half): the tile's rank by
+// falling length, task number 2 rank + half, dealt to the four waves in snake order (0 1 2 3 3 2 1 0 0 1 ...): the
+// two halves of a tile start together on two waves (the second reader of a B block finds it in L1) and the waves'
+// slab totals differ by a few per cent (54 / 54 / 50 / 50 on the canonical bank).  All-padding tiles get no task.
+__device__ __forceinline__ void chain_tile_range(const int32_t* __restrict__ meta, int nslab, ChainLds* cl, int c) {
+    int lo = nslab, hi = 0;
+    for (int q = 0; q < nslab; ++q)
+        if (((uint32_t)meta[CSC_TILE_COLS + q] >> c) & 1u) { lo = min(lo, q); hi = q + 1; }
+    cl->range[c] = (unsigned short)(min(lo, hi) | (hi << 8));
+    if (c < WG / 64) cl->desc[c][TASK_SLOTS - 1] = 0u;                  // the waves' task counts, raised below
+}
+__device__ __forceinline__ void chain_deal_task(ChainLds* cl, int t, int P) {
+    const int c = t >> 1, rh = t & 1;
+    const int pk = cl->range[c], lo = pk & 0xff, hi = pk >> 8, len = hi - lo;
+    if (len <= 0 || 128 * rh >= P) return;
+    int rank = 0;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        const int pq = cl->range[q], lq = (pq >> 8) - (pq & 0xff);
+        rank += (lq > len || (lq == len && q < c)) ? 1 : 0;
+    }
+    const int n = 2 * rank + rh;                                      // task number, longest first
+    const int w = (n & 4) ? 3 - (n & 3) : (n & 3);
+    cl->desc[w][n >> 2] = (unsigned)c | ((unsigned)rh << 4) | ((unsigned)lo << 8) | ((unsigned)hi << 16);
+    atomicMax(&cl->desc[w][TASK_SLOTS - 1], (unsigned)(n >> 2) + 1u);
+}
 
-template <bool COLS>
+// The wave's tasks of one node.  FINAL: candidates by the given threshold `tau_fix` (the rare second pass behind a
+// raw-list overflow) instead of the running maximum.  DUMP (test aid, csc_filter_product): the finished tasks'
+// products go to dump[p * K + atom] as they are.
+// No vector-memory operation of this wave may be in flight on entry (the loop's vmcnt counts assume its own loads).
+template <bool FINAL, bool DUMP>
+__device__ __forceinline__ void chain_product16(const _Float16* __restrict__ bank16, const int* perm, ChainLds* cl,
+                                                const _Float16* r16, unsigned mydesc, int nt, int K, int P,
+                                                float band, float tau_fix, float* __restrict__ dump) {
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    const _Float16* pa0 = r16 + (lr & 7) * R16_CS + (lr & 8) + 8 * lq;       // + 128 row half + 16 u
+    const _Float16* bl = bank16 + lane * 8;
+    f16x8 W[10], Bf[BD];
+    f32x4 acc[8];
+    int cur_c = 0, cur_rh = 0, s0 = 0, s1 = 1;
+    const _Float16* pa = pa0;
+    const _Float16* bp = bl;
+    auto begin_task = [&](int it) __attribute__((always_inline)) {
+        const unsigned d = (unsigned)__builtin_amdgcn_readlane((int)mydesc, it);
+        cur_c = (int)(d & 15u); cur_rh = (int)((d >> 4) & 1u); s0 = (int)((d >> 8) & 255u); s1 = (int)((d >> 16) & 255u);
+        pa = pa0 + 128 * cur_rh;
+        bp = bl + cur_c * BLKF;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) W[i] = *reinterpret_cast<const f16x8*>(pa + 16 * (2 * s0 + i));
+        // (a task shorter than BD slabs re-loads its last one: the load count stays fixed)
+#pragma unroll
+        for (int q = 0; q < BD; ++q) Bf[q] = *reinterpret_cast<const f16x8*>(bp + min(s0 + q, s1 - 1) * SLABF);
+    };
+    // LDS byte offset of the running maximum (for the hand-written ds_max_u32 below)
+    const unsigned key_off = (unsigned)(size_t)(lptr_t)&cl->gkey;
+    auto epilogue = [&](int c, int rh) __attribute__((always_inline)) {
+        // The finished task's 128 x 16 correlations: entries outside the matrix out, maximum, running maximum, candidates.
+        // Kept short on purpose: 18 of these per node share the SIMD's vector issue with the other waves' MFMAs.
+        const int atom = perm[16 * c + lr];
+        const int prow = 128 * rh + 4 * lq;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+            if (128 * rh + 16 * mi + 15 >= P) {                          // (uniform; the last row tile only)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    if (prow + 16 * mi + rg >= P) acc[mi][rg] = -INFINITY;
+            }
+        if (DUMP) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int p = prow + 16 * mi + rg;
+                    if (p < P && atom >= 0) dump[(size_t)p * K + atom] = acc[mi][rg];
+                }
+        }
+        // the lane's maximum: two chains of v_max3_f32 (NaN operands are skipped, like fmaxf)
+        float m0 = vmax3(acc[0][0], acc[0][1], acc[0][2]), m1 = vmax3(acc[0][3], acc[1][0], acc[1][1]);
+        m0 = vmax3(m0, acc[1][2], acc[1][3]); m1 = vmax3(m1, acc[2][0], acc[2][1]);
+        m0 = vmax3(m0, acc[2][2], acc[2][3]); m1 = vmax3(m1, acc[3][0], acc[3][1]);
+        m0 = vmax3(m0, acc[3][2], acc[3][3]); m1 = vmax3(m1, acc[4][0], acc[4][1]);
+        m0 = vmax3(m0, acc[4][2], acc[4][3]); m1 = vmax3(m1, acc[5][0], acc[5][1]);
+        m0 = vmax3(m0, acc[5][2], acc[5][3]); m1 = vmax3(m1, acc[6][0], acc[6][1]);
+        m0 = vmax3(m0, acc[6][2], acc[6][3]); m1 = vmax3(m1, acc[7][0], acc[7][1]);
+        float lmax = vmax3(m0, m1, vmax3(acc[7][2], acc[7][3], -INFINITY));
+        if (atom < 0) lmax = -INFINITY;
+        float thr = tau_fix;
+        if (!FINAL) {
+            // Every lane raises the node's running maximum by its own (one ds_max_u32: the LDS serialises the 64 lanes,
+            // no wave reduction on the vector pipe) and reads it back: the tasks finished before and all of this one.
+            // (A NaN product gives the key of a NaN, above +inf: nothing is a candidate.)
+            // (hand-written, wait included: a volatile read through the generic pointer became a FLAT load that waited
+            // for the next task's B fragments, vmcnt(0), in every epilogue)
+            unsigned cur;
+            asm volatile("ds_max_u32 %1, %2\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(cur) : "v"(key_off), "v"(fkey(lmax)) : "memory");
+            thr = fkey_inv(cur) - band;
+        }
+        if (lmax >= thr) {
+            uint32_t mk = 0u;
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) mk |= (acc[mi][rg] >= thr) ? (1u << (4 * mi + rg)) : 0u;
+            while (mk) {
+                const int e = __builtin_ctz(mk);
+                mk &= mk - 1;
+                float v = acc[0][0];
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) v = (e == 4 * mi + rg) ? acc[mi][rg] : v;
+                const int at = atomicAdd(&cl->raw_cnt, 1);
+                if (at < RAW_CAP) {
+                    cl->raw_idx[at] = (prow + 16 * (e >> 2) + (e & 3)) * K + atom;
+                    cl->raw_val[at] = v;
+                }
+            }
+        }
+    };
+    if (nt <= 0) return;
+#ifdef CSC_PHASE_PROF
+    // (two stamps per product only: a stamp is an s_memtime + a full LDS-counter wait, three per task distorted the loop)
+    const unsigned long long pt_start = __builtin_readcyclecounter();
+    unsigned long long pt_steps = 0;
+#endif
+    begin_task(0);
+    for (int it = 0; it < nt; ++it) {
+#ifdef CSC_PHASE_PROF
+        pt_steps += (unsigned long long)(s1 - s0);
+#endif
+        int s = s0;
+        const int sl = s1 - 1;
+        auto step = [&](auto phc, auto firstc) __attribute__((always_inline)) {
+            constexpr int PH = decltype(phc)::value;
+            constexpr bool FIRST = decltype(firstc)::value;
+            W[(2 * PH + 8) % 10] = *reinterpret_cast<const f16x8*>(pa + 16 * (2 * s + 8));
+            W[(2 * PH + 9) % 10] = *reinterpret_cast<const f16x8*>(pa + 16 * (2 * s + 9));
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+                acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[(2 * PH + mi) % 10], Bf[PH],
+                                                                 FIRST ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mi], 0, 0, 0);
+            // the fragment BD slabs ahead; past the task's end the SAME number of loads goes out (the vmcnt counts are
+            // static), every lane reading one 16-byte piece: one cache line for the wave instead of eight
+            if (s + BD <= sl) Bf[PH] = *reinterpret_cast<const f16x8*>(bp + (s + BD) * SLABF);
+            else Bf[PH] = *reinterpret_cast<const f16x8*>(bank16);
+            ++s;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        step(std::integral_constant<int, 0>{}, std::true_type{});
+        // whole rounds of five slabs in a loop with ONE way round (a `break` inside the round lets the compiler merge
+        // the exits' load states into the loop header: a full vmcnt(0) drain every round), then the rest
+        const int nrest = s1 - s;
+        const int rounds = nrest / BD, rem = nrest - rounds * BD;
+        for (int q = 0; q < rounds; ++q) {
+            step(std::integral_constant<int, 1>{}, std::false_type{});
+            step(std::integral_constant<int, 2>{}, std::false_type{});
+            step(std::integral_constant<int, 3>{}, std::false_type{});
+            step(std::integral_constant<int, 4>{}, std::false_type{});
+            step(std::integral_constant<int, 0>{}, std::false_type{});
+        }
+        if (rem >= 1) {
+            step(std::integral_constant<int, 1>{}, std::false_type{});
+            if (rem >= 2) {
+                step(std::integral_constant<int, 2>{}, std::false_type{});
+                if (rem >= 3) {
+                    step(std::integral_constant<int, 3>{}, std::false_type{});
+                    if (rem >= 4) step(std::integral_constant<int, 4>{}, std::false_type{});
+                }
+            }
+        }
+        const int done_c = cur_c, done_rh = cur_rh;
+        if (it + 1 < nt) begin_task(it + 1);
+        epilogue(done_c, done_rh);
+    }
+#ifdef CSC_PHASE_PROF
+    if (threadIdx.x == 0) {                                           // wave 0's own clocks: slots 28, 31
+        atomicAdd(&g_prof[28][blockIdx.x % PROF_BUCKETS], __builtin_readcyclecounter() - pt_start);
+        atomicAdd(&g_prof[31][blockIdx.x % PROF_BUCKETS], pt_steps);
+    }
+#endif
+}
+
 __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
     extern __shared__ double lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lr = lane & 15, lq = lane >> 4;
     const int N = a.N, K = a.K, L = a.L, d0 = a.depth;
     const int nslab = (L + SLAB - 1) / SLAB;
 
-    // ---- LDS carve-up: ring [LRING][GBLK] halves (COLS: [4 waves][LEAN_AHEAD][BLKF]) | r64 [Npad] |
-    // r16 [R16_COPIES][R16_CS] | NodeLds | LeanLds | COLS: ColsLds
+    // ---- LDS carve-up: r64 [Npad] | r16 [R16_COPIES][R16_CS] | NodeLds | ChainLds
     const int Npad = (N + 3) & ~3;
-    _Float16* ring = reinterpret_cast<_Float16*>(lds_raw);
-    double* r64 = lds_raw + (COLS ? (WG / 64) * LEAN_AHEAD * BLKF : LRING * GBLK) / 4;
+    double* r64 = lds_raw;
     _Float16* r16 = reinterpret_cast<_Float16*>(r64 + Npad);
     NodeLds* sl = reinterpret_cast<NodeLds*>(r16 + R16_COPIES * R16_CS);
-    LeanLds* ll = reinterpret_cast<LeanLds*>(sl + 1);
-    ColsLds* cl = reinterpret_cast<ColsLds*>(ll + 1);
+    ChainLds* cl = reinterpret_cast<ChainLds*>(sl + 1);
 
     const int Fd = a.ts.F[d0];                                        // = F of every level below (one child per node)
     size_t s;
@@ -1877,18 +1759,13 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
     node_of_block(Fd, s, j);
     if (tid >= 192 && tid < 192 + MAX_SLABS) sl->masks[tid - 192] = (uint32_t)a.meta[CSC_TILE_COLS + tid - 192];
     if (tid < CSC_TILE_COLS) sl->perm[tid] = a.meta[tid];
-    if (COLS && tid < NT) {
-        // live slabs of column tile `tid` (outside them its blocks are zero padding)
-        int lo = nslab, hi = 0;
-        for (int q = 0; q < nslab; ++q)
-            if (((uint32_t)a.meta[CSC_TILE_COLS + q] >> tid) & 1u) { lo = min(lo, q); hi = q + 1; }
-        cl->crange[tid] = (unsigned short)(min(lo, hi) | (hi << 8));
-    }
+    if (tid >= 160 && tid < 160 + NT) chain_tile_range(a.meta, nslab, cl, tid - 160);
 
     PROF_INIT(16);
     const double* rin = (d0 == 0 || a.from_root) ? a.signals + s * (size_t)N : a.ws[d0 & 1] + (s * Fd + j) * (size_t)a.NS;
     double rnorm2, first[4];
     node_prologue(a, sl, r64, nullptr, Npad, 0, rin, s, j, rnorm2, first, a.from_root ? 0 : d0);
+    if (tid >= 64 && tid < 64 + 2 * NT) chain_deal_task(cl, tid - 64, a.P);   // (behind the prologue's barrier)
     if (a.from_root) {
         // d0 = 1 and the root level left only its pick: this node is the signal's child (pos, atom) with <atom, signal>
         // parked in its MSE slot.  Its least squares, residual, factor and MSE are child_solve_and_write's at depth 0,
@@ -1909,43 +1786,10 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
     const float am2 = *a.amax2, am = sqrtf(am2);
     const float band = 2.f * ((9.765625e-04f + DELTA_REL + 1e-6f) * am + 2.9802322e-08f * sqrtf((float)L) * (1.f + am));
     if (tid == 0) a.flags[s * Fd + j] = 0;
-    if (COLS) {
-        // the column tiles by falling number of live slabs, dealt longest first to the least loaded wave
-        if (tid < NT) {
-            const int pk = cl->crange[tid], len = (pk >> 8) - (pk & 0xff);
-            int rank = 0;
-            for (int c = 0; c < NT; ++c) {
-                const int pc = cl->crange[c], lc = (pc >> 8) - (pc & 0xff);
-                rank += (lc > len || (lc == len && c < tid)) ? 1 : 0;
-            }
-            cl->order[rank] = (unsigned short)(tid | (len << 8));
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int load[WG / 64] = {0, 0, 0, 0}, cnt[WG / 64] = {0, 0, 0, 0};
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int o = cl->order[i];
-                int w = 0;
-#pragma unroll
-                for (int q = 1; q < WG / 64; ++q) w = load[q] < load[w] ? q : w;
-#pragma unroll
-                for (int q = 0; q < WG / 64; ++q)
-                    if (q == w) { cl->witem[q][1 + cnt[q]] = (unsigned char)(o & 0xff); ++cnt[q]; load[q] += (o >> 8) + 1; }
-            }
-#pragma unroll
-            for (int q = 0; q < WG / 64; ++q) cl->witem[q][0] = (unsigned char)cnt[q];
-        }
-    } else if (tid < NT / NG) {
-        // group g's blocks hold a non-zero only in slabs whose first non-zero tile is below 3 (g + 1)
-        int lo = nslab, hi = 0;
-        for (int q = 0; q < nslab; ++q) {
-            const uint32_t m = sl->masks[q];
-            if (m && (int)__builtin_ctz(m) < NG * (tid + 1)) { lo = min(lo, q); hi = q + 1; }
-        }
-        ll->s0[tid] = min(lo, hi);
-        ll->s1[tid] = hi;
-    }
+    __syncthreads();                                                  // the task table
+    // the wave's task descriptors ride in a register: lane i holds descriptor i
+    const unsigned mydesc = cl->desc[wave][lane & (TASK_SLOTS - 1)];
+    const int nt = __builtin_amdgcn_readfirstlane((int)cl->desc[wave][TASK_SLOTS - 1]);
 
     // The chain cannot go on in fp16 at level d: the node's state goes to its workspace row (level d0's is still
     // there) and the flag tells the follow-up kernel where to take over.  Workgroup-uniform.
@@ -1961,9 +1805,6 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
         if (tq == 0) { a.flags[s * Fd + j] = (uint8_t)(d + 1); if (a.stats) atomicAdd(&a.stats[3], 1); }
     };
 
-    f32x4 acc[MT][NG];
-    int permv[NG];
-    const int prow = 64 * wave + 4 * lq;
     // ---- the chain: this node, its child, its grandchild ... down to the leaves; the residual, the Cholesky
     // factor and the coefficients stay in LDS from one level to the next, only the node tables go to HBM
     for (int d = d0; d < a.Kmax; ++d) {
@@ -1983,140 +1824,49 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
             }
             build_r16(r64, N, inv, win, r16);
         }
-        if (tid == 0) {
-            sl->cand_cnt = 0;
-            if (COLS) { cl->raw_cnt = 0; cl->gkey = fkey(-INFINITY); } else ll->gkey = fkey(-INFINITY);
-        }
+        if (tid == 0) { sl->cand_cnt = 0; cl->raw_cnt = 0; cl->gkey = fkey(-INFINITY); }
+        WAIT_VM(0);                                                   // (the product counts its own loads)
         __syncthreads();
 #ifdef CSC_PHASE_PROF
         const unsigned trace_t0 = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
-        if constexpr (COLS) {
-            // ---- one sweep, a wave per column tile; candidates against the running maximum ------------------------
-            lean_cols16(a, sl, cl, r16, ring, band);
-            __syncthreads();
-            PROF_MARK(1);
+        // ---- ONE sweep; every task's candidates against the running maximum ------------------------------------------
+        chain_product16<false, false>(a.bank16, sl->perm, cl, r16, mydesc, nt, K, a.P, band, 0.f, nullptr);
+        __syncthreads();
+        PROF_MARK(1);
 #ifdef CSC_PHASE_PROF
-            if (tid == 0) {
-                const unsigned at = atomicAdd(&g_trace_n, 1u);
-                if (at < TRACE_CAP) {
-                    g_trace[at][0] = __builtin_amdgcn_s_getreg(63492);
-                    g_trace[at][1] = trace_t0;
-                    g_trace[at][2] = (unsigned)__builtin_amdgcn_s_memtime();
-                    g_trace[at][3] = blockIdx.x | ((__builtin_amdgcn_s_getreg(6164) & 15u) << 24) | ((unsigned)d << 28);
-                }
+        if (tid == 0) {
+            const unsigned at = atomicAdd(&g_trace_n, 1u);
+            if (at < TRACE_CAP) {
+                g_trace[at][0] = __builtin_amdgcn_s_getreg(63492);
+                g_trace[at][1] = trace_t0;
+                g_trace[at][2] = (unsigned)__builtin_amdgcn_s_memtime();
+                g_trace[at][3] = blockIdx.x | ((__builtin_amdgcn_s_getreg(6164) & 15u) << 24) | ((unsigned)d << 28);
             }
+        }
 #endif
-            const int nraw = cl->raw_cnt;
-            if (nraw > RAW_CAP) { give_up(d); return; }               // (uniform) a flat residual: fp32
-            const float tau = fkey_inv(cl->gkey) - band;
+        int nraw = cl->raw_cnt;
+        const float tau = fkey_inv(cl->gkey) - band;
+        if (nraw > RAW_CAP) {
+            // (uniform, rare) the early thresholds let too many entries through: once more, with the final band
+            __syncthreads();
+            if (tid == 0) cl->raw_cnt = 0;
+            __syncthreads();
+            chain_product16<true, false>(a.bank16, sl->perm, cl, r16, mydesc, nt, K, a.P, band, tau, nullptr);
+            __syncthreads();
+            nraw = cl->raw_cnt;
+            if (nraw > RAW_CAP) { give_up(d); return; }               // a flat residual: fp32
+        }
+        {
             int tq = threadIdx.x;
             asm volatile("" : "+v"(tq));
             for (int i = tq; i < nraw; i += WG)
                 if (cl->raw_val[i] >= tau) {
                     const int slot = atomicAdd(&sl->cand_cnt, 1);
+                    // candidates 128 .. 255 wait in the space of the float64 scores, which nobody has written yet
                     if (slot < CAND_CAP) sl->cand_idx[slot] = cl->raw_idx[i];
                     else if (slot < 2 * CAND_CAP) reinterpret_cast<int*>(sl->cand_val)[slot - CAND_CAP] = cl->raw_idx[i];
                 }
-        } else {
-            // ---- ONE sweep: a group's candidates are taken while it is in registers, against the node's running maximum
-            // (the groups before, and this wave's own share of this one: a lower bound of the final maximum, so the
-            // entries kept are a superset), a bound of the value beside the index; the final band filters them behind the sweep.  Narrow
-            // atoms first: their group holds the maximum most often (2 of 3 nodes on config 2), which keeps the early
-            // thresholds tight.  Only when more than CAND_CAP entries pass the early thresholds is there a second sweep
-            // with the final one (the round-1 scheme: every group in the band multiplied again)
-            auto collect = [&](int g, float thr, bool early, float lbound) {
-                uint32_t mk[2] = {0u, 0u};
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-                        for (int nj = 0; nj < NG; ++nj) {
-                            const int e = (4 * mi + rg) * NG + nj;
-                            mk[e >> 5] |= (acc[mi][nj][rg] >= thr) ? (1u << (e & 31)) : 0u;
-                        }
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    uint32_t mm = mk[w];
-                    while (mm) {
-                        const int e = 32 * w + __builtin_ctz(mm);
-                        mm &= mm - 1;
-                        const int r = e / NG, nj = e - r * NG;
-                        const int idx = (prow + 16 * (r >> 2) + (r & 3)) * K + sl->perm[16 * (NG * g + nj) + lr];
-                        const int slot = atomicAdd(&sl->cand_cnt, 1);
-                        if (early) {
-                            // beside the index goes the LANE's maximum, an upper bound of the entry: the final filter then
-                            // keeps a few entries too many (re-scored in float64 like the rest) and never one too few
-                            if (slot < CAND_CAP) {
-                                sl->cand_idx[slot] = idx;
-                                reinterpret_cast<float*>(sl->cand_val)[slot] = lbound;
-                            }
-                        } else {
-                            // candidates 128 .. 255 wait in the space of the float64 scores, which nobody has written yet
-                            if (slot < CAND_CAP) sl->cand_idx[slot] = idx;
-                            else if (slot < 2 * CAND_CAP) reinterpret_cast<int*>(sl->cand_val)[slot - CAND_CAP] = idx;
-                        }
-                    }
-                }
-            };
-            for (int g = 0; g < NT / NG; ++g) {
-                bool lane_supp;
-                gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
-                const float lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, 0, permv, acc, lane_supp);
-                const float bv = wave_max(lmax);
-                unsigned cur = 0;
-                if (lane == 63) {
-                    ll->wgmax[g][wave] = bv;                              // read behind the barrier below
-                    const unsigned mine = fkey(bv == bv ? bv : -INFINITY);
-                    const unsigned old = atomicMax(&ll->gkey, mine);
-                    cur = old > mine ? old : mine;
-                }
-                const float tauw = fkey_inv((unsigned)__builtin_amdgcn_readlane((int)cur, 63)) - band;
-                if (lmax >= tauw) collect(g, tauw, true, lmax);
-            }
-            __syncthreads();
-            float gmax[NT / NG];
-#pragma unroll
-            for (int g = 0; g < NT / NG; ++g)
-                gmax[g] = fmaxf(fmaxf(ll->wgmax[g][0], ll->wgmax[g][1]), fmaxf(ll->wgmax[g][2], ll->wgmax[g][3]));
-            PROF_MARK(1);
-#ifdef CSC_PHASE_PROF
-            if (tid == 0) {
-                const unsigned at = atomicAdd(&g_trace_n, 1u);
-                if (at < TRACE_CAP) {
-                    g_trace[at][0] = __builtin_amdgcn_s_getreg(63492);
-                    g_trace[at][1] = trace_t0;
-                    g_trace[at][2] = (unsigned)__builtin_amdgcn_s_memtime();
-                    g_trace[at][3] = blockIdx.x | ((__builtin_amdgcn_s_getreg(6164) & 15u) << 24) | ((unsigned)d << 28);
-                }
-            }
-#endif
-            const float m32 = fmaxf(fmaxf(gmax[0], gmax[1]), gmax[2]);
-            const float tau = m32 - band;
-            const int nraw = sl->cand_cnt;
-            int tq = threadIdx.x;
-            asm volatile("" : "+v"(tq));
-            if (nraw <= CAND_CAP) {                                       // (uniform) the early entries, by the final band
-                int keep = -1;
-                if (tq < nraw && reinterpret_cast<const float*>(sl->cand_val)[tq] >= tau) keep = sl->cand_idx[tq];
-                __syncthreads();
-                if (tq == 0) sl->cand_cnt = 0;
-                __syncthreads();
-                if (keep >= 0) sl->cand_idx[atomicAdd(&sl->cand_cnt, 1)] = keep;
-            } else {
-                // ---- sweep 2 (rare): the groups that reach the band are multiplied again, candidates by the final band
-                __syncthreads();                                          // (everybody has read nraw)
-                if (tq == 0) sl->cand_cnt = 0;
-                __syncthreads();
-                for (int g = 0; g < NT / NG; ++g) {
-                    if (!(gmax[g] >= tau)) continue;                      // uniform
-                    bool lane_supp;
-                    gemm16_group(a.bank16, g, ll->s0[g], ll->s1[g], r16, ring, acc);
-                    const float lmax = group_finish(a, sl, ll->sib_pos, ll->sib_atom, g, 0, permv, acc, lane_supp);
-                    if (lmax >= tau) collect(g, tau, false, lmax);
-                }
-            }
         }
         __syncthreads();
         PROF_MARK(3);
@@ -2157,16 +1907,14 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
     PROF_MARK(9);
 }
 
-__global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a) { lean_chain<false>(a); }
-// the same chain with the column-owner product: 64 accumulator + 80 window registers, three workgroups per CU
-__global__ __launch_bounds__(WG, 3) void mmp_level_cols_kernel(const LevelArgs a) { lean_chain<true>(a); }
+__global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a) { lean_chain(a); }
 
 // ------------------------------------------------------------------------------------------------
 // test aid: the fp16 filter product itself (what the level kernels only ever hold in registers)
 // ------------------------------------------------------------------------------------------------
 // out[b][p][k] = the fp16 matrix-core product of signal b scaled to unit norm with atom k at shift p, in units of
 // ||signal||, taken by the very loops the level kernels use: variant 0 = corr_tile_gemm16 (mmp_level_kernel),
-// variant 1 = gemm16_group over the three column groups (mmp_level_lean_kernel).  eps[b] = the rounding bound the
+// variant 1 = chain_product16, the wave-private tasks of the chain kernel (mmp_level_lean_kernel).  eps[b] = the rounding bound the
 // kernels assume for an entry (half their candidate band); norm[b] = ||signal||.  tests/test_gpu_filter_bound.py
 // checks |out - float64| <= eps on golden residuals and adversarial operands.
 __global__ __launch_bounds__(WG, 2) void filter_product_kernel(const _Float16* __restrict__ bank16,
@@ -2178,12 +1926,12 @@ __global__ __launch_bounds__(WG, 2) void filter_product_kernel(const _Float16* _
     __shared__ uint32_t masks[MAX_SLABS];
     __shared__ int perm[CSC_TILE_COLS];
     __shared__ double wsum[WG / 64];
-    __shared__ int gs0[NT / NG], gs1[NT / NG];
+    __shared__ ChainLds cls;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int nslab = (L + SLAB - 1) / SLAB;
     const int Npad = (N + 3) & ~3;
-    _Float16* ring = reinterpret_cast<_Float16*>(lds_raw);            // [RING16][SLABF] halves (>= [LRING][GBLK])
+    _Float16* ring = reinterpret_cast<_Float16*>(lds_raw);            // [RING16][SLABF] halves
     double* r64 = lds_raw + (RING16 * SLABF) / 4;
     _Float16* r16 = reinterpret_cast<_Float16*>(r64 + Npad);
     const size_t b = blockIdx.x;
@@ -2204,15 +1952,10 @@ __global__ __launch_bounds__(WG, 2) void filter_product_kernel(const _Float16* _
     if (lane == 63) wsum[wave] = ss;
     __syncthreads();
     const double rnorm2 = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    if (tid < NT / NG) {
-        int lo = nslab, hi = 0;
-        for (int q = 0; q < nslab; ++q) {
-            const uint32_t m = masks[q];
-            if (m && (int)__builtin_ctz(m) < NG * (tid + 1)) { lo = min(lo, q); hi = q + 1; }
-        }
-        gs0[tid] = min(lo, hi);
-        gs1[tid] = hi;
-    }
+    if (tid >= 160 && tid < 160 + NT) chain_tile_range(meta, nslab, &cls, tid - 160);
+    if (tid == 0) { cls.raw_cnt = 0; cls.gkey = fkey(-INFINITY); }
+    __syncthreads();
+    if (tid >= 64 && tid < 64 + 2 * NT) chain_deal_task(&cls, tid - 64, P);
     const float am = sqrtf(*amax2);
     if (tid == 0) {
         eps[b] = (9.765625e-04f + DELTA_REL + 1e-6f) * am + 2.9802322e-08f * sqrtf((float)L) * (1.f + am);
@@ -2236,19 +1979,18 @@ __global__ __launch_bounds__(WG, 2) void filter_product_kernel(const _Float16* _
                     if (p < P && k >= 0) out[(b * P + p) * K + k] = acc[mi][ni][rg];
                 }
     } else {
-        for (int g = NT / NG - 1; g >= 0; --g) {
-            f32x4 acc[MT][NG];
-            gemm16_group(bank16, g, gs0[g], gs1[g], r16, ring, acc);
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                for (int nj = 0; nj < NG; ++nj)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const int p = prow + 16 * mi + rg, k = perm[16 * (NG * g + nj) + lr];
-                        if (p < P && k >= 0) out[(b * P + p) * K + k] = acc[mi][nj][rg];
-                    }
+        // column tiles that are all padding belong to no task: their (valid) entries are exact zeros
+        for (int c = 0; c < NT; ++c) {
+            bool live = false;
+            for (int q = 0; q < nslab; ++q) live |= ((masks[q] >> c) & 1u) != 0u;
+            const int k = perm[16 * c + lr];
+            if (!live && k >= 0)
+                for (int p = tid >> 4; p < P; p += WG / 16) out[(b * P + p) * K + k] = 0.f;
         }
+        const unsigned mydesc = cls.desc[wave][lane & (TASK_SLOTS - 1)];
+        const int nt = __builtin_amdgcn_readfirstlane((int)cls.desc[wave][TASK_SLOTS - 1]);
+        WAIT_VM(0);
+        chain_product16<true, true>(bank16, perm, &cls, r16, mydesc, nt, K, P, 0.f, INFINITY, out + b * (size_t)P * K);
     }
 }
 
@@ -3847,9 +3589,8 @@ static size_t node_ws_bytes(int S, int N, int max_sparsity, const TreeShape& ts)
 static size_t flag_ws_bytes(int S, int max_sparsity, const TreeShape& ts) {      // one byte per frontier node
     return ((size_t)S * frontier_max(max_sparsity, ts) + 15) & ~(size_t)15;
 }
-static size_t lean_lds_bytes(int N, bool cols) {
-    return (cols ? (size_t)(WG / 64) * LEAN_AHEAD * BLKF * 2 + sizeof(ColsLds) : (size_t)LRING * GBLK * 2) +
-           (size_t)ceil4(N) * 8 + R16_COPIES * R16_CS * 2 + sizeof(NodeLds) + sizeof(LeanLds);
+static size_t lean_lds_bytes(int N) {
+    return (size_t)ceil4(N) * 8 + R16_COPIES * R16_CS * 2 + sizeof(NodeLds) + sizeof(ChainLds);
 }
 
 size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections, int branches) {
@@ -3920,8 +3661,6 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (!tiled) hipFuncSetAttribute((const void*)mmp_level_followup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds);
-    if (lean) hipFuncSetAttribute((const void*)mmp_level_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lean_lds_bytes(N, true));
 
     double* ws[2] = {static_cast<double*>(d_workspace), static_cast<double*>(d_workspace) + node_bytes / 16};
     hipStream_t st = (hipStream_t)stream;
@@ -3982,12 +3721,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
             a.flags = node_flags;
             a.from_root = picked ? 1 : 0;
             chain = true;
-            // CSC_FLAG_LEAN_COLS: the same chain with the column-owner product (an experiment that lost, DESIGN.md §9;
-            // identical records)
-            if (flags & CSC_FLAG_LEAN_COLS)
-                hipLaunchKernelGGL(mmp_level_cols_kernel, dim3((unsigned)grid), dim3(WG), lean_lds_bytes(N, true), st, a);
-            else
-                hipLaunchKernelGGL(mmp_level_lean_kernel, dim3((unsigned)grid), dim3(WG), lean_lds_bytes(N, false), st, a);
+            hipLaunchKernelGGL(mmp_level_lean_kernel, dim3((unsigned)grid), dim3(WG), lean_lds_bytes(N), st, a);
             hipLaunchKernelGGL(mmp_level_followup_kernel, dim3((unsigned)((grid + FOLLOW_NODES - 1) / FOLLOW_NODES)),
                                dim3(WG), lds, st, a);                // the chains it gave up: fp32
         } else {

@@ -144,12 +144,9 @@ class DeviceBank:
         # correlations on the fp16 matrix cores as a filter in front of the float64 re-score (same results);
         # set to True to correlate in fp32 only (CSC_FLAG_FP32_ONLY)
         self.fp32_only = False
-        # single-child tree levels on the column-group ("lean") kernel, four nodes per CU (same results);
+        # single-child tree levels on the chain ("lean") kernel, four nodes per CU (same results);
         # set to False to keep them on the register-resident kernel (CSC_FLAG_NO_LEAN)
         self.lean = True
-        # set to True to run those chains with the column-owner product (CSC_FLAG_LEAN_COLS: an experiment kept for
-        # comparison -- identical records, slower)
-        self.lean_cols = False
 
     def similarity_table(self, N: int, threshold: float):
         key = (int(N), float(threshold))
@@ -326,8 +323,7 @@ class DeviceBank:
                     "rec_sel": rec[:, 16 * K:].view(torch.int32).unflatten(1, (K, K, 2)),
                     "stats": torch.zeros(4, dtype=torch.int32, device=dev),
                 }
-            flags = ((1 if self.fp32_only else 0) | (0 if self.lean else 2) | 4 |       # 4 = CSC_FLAG_RECORDS_AOS
-                     (8 if self.lean_cols else 0))
+            flags = (1 if self.fp32_only else 0) | (0 if self.lean else 2) | 4        # 4 = CSC_FLAG_RECORDS_AOS
             tail = (_ptr(out["node_pos"]), _ptr(out["node_atom"]), _ptr(out["node_mse"]), _ptr(out["node_coef"]),
                     _ptr(out["rec_buf"]), None, None, _ptr(out["stats"]), _stream(dev))
             head = (_ptr(self.bank32t), _ptr(self.bank64), _ptr(sim), self.K, self.L, _ptr(sig), S, N,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CSC_ABI_VERSION 4
+#define CSC_ABI_VERSION 5
 #define CSC_TILE_COLS 144      /* atoms per column tile of the correlation kernel (9 x 16)   */
 #define CSC_TILE_ROWS 256      /* positions per row tile (4 waves x 4 x 16)                   */
 #define CSC_MAX_SPARSITY 16    /* largest tree depth / support size                           */
@@ -34,7 +34,6 @@ extern "C" {
 #define CSC_FLAG_FP32_ONLY 1   /* csc_mmpdf_batch flags: skip the fp16 matrix-core filter      */
 #define CSC_FLAG_NO_LEAN 2     /* keep single-child levels on the register-resident kernel      */
 #define CSC_FLAG_RECORDS_AOS 4 /* per-sparsity records as one contiguous record per signal      */
-#define CSC_FLAG_LEAN_COLS 8   /* chain kernel: the column-owner product (experiment, same records) */
 #define CSC_STATIC_SCRATCH_BYTES (64u << 20)   /* static device scratch of csc_mmpdf_batch_static      */
 
 int csc_abi_version(void);
@@ -93,11 +92,9 @@ size_t csc_mmpdf_workspace_bytes(int S, int N, int max_sparsity, int connections
  *               within the fp16 rounding bound of the maximum is re-scored in float64; the selections are
  *               the float64 arg-max either way (identical results, the flag exists to check that).
  *               CSC_FLAG_NO_LEAN: tree levels on which every node has one child normally run on a kernel
- *               that takes the fp16 product in three column groups (four nodes per CU instead of two) and
- *               walks each chain of such nodes down to its leaf in one launch; the flag keeps them on the
- *               register-resident kernel, one launch per level (identical results, same purpose)
- *               CSC_FLAG_LEAN_COLS: those chains with the column-owner product (a wave per 16-column bank tile
- *               against all row tiles; an experiment kept for comparison: identical results, slower)
+ *               that takes the fp16 product in wave-private (128 position x 16 column) tasks (four nodes per CU
+ *               instead of two) and walks each chain of such nodes down to its leaf in one launch; the flag keeps
+ *               them on the register-resident kernel, one launch per level (identical results, same purpose)
  *   d_signals   [S][N] f64
  *   d_node_pos  [S][NN] int32   selected position of the node      (src/csc/mmp.py:74-76)
  *   d_node_atom [S][NN] int32   selected atom index
@@ -157,7 +154,7 @@ int csc_mmpdf_batch_static(const float* d_bank32t, const double* d_bank64, const
  * correlations are float64, src/csc/dictionary.py:395-407).
  *   d_prod [B][P][K] f32: product of signal b, scaled to unit norm and rounded to fp16, with the fp16 bank, in
  *          units of ||signal_b||; variant 0 = the loop of the register-resident level kernel, 1 = the
- *          column-group loop of the chain kernel
+ *          wave-private task loop of the chain kernel
  *   d_eps  [B] f32: the bound on |d_prod - float64 correlation / ||signal||| the kernels assume (their
  *          candidate band is twice this);   d_norm [B] f64: ||signal_b||
  * Covers what the filter covers: K <= 144, P <= 256, L <= 512, N <= 1024. */

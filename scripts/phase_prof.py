@@ -34,3 +34,7 @@ for title, base, nodes in rows:
     for n, x in zip(names, w):
         print(f"  {n:18s} {x / nodes:10.0f} clk/node  {100 * x / max(tot, 1):5.1f} %")
     print(f"  total {tot / nodes:.0f} clk/node")
+
+if lean:
+    n = 3200 * 12
+    print("chain product, wave 0 per node: %.0f clk for %.1f slab steps (128 clk of MFMAs each)" % (v[28] / n, v[31] / n))

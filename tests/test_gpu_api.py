@@ -660,26 +660,3 @@ def test_reference_defaults_crowded_bands(dic, config2):
     assert np.array_equal(a.node_pos, r.node_pos) and np.array_equal(a.node_atom, r.node_atom)
     assert np.allclose(a.node_mse, r.node_mse, rtol=1e-11, atol=0)
     assert a.stats[0] == 0 and a.stats[3] <= 10, a.stats
-
-
-@pytest.mark.parametrize("tree", [(5, 3, 3), (10, 3, 10), (7, 4, 4)])
-def test_column_owner_chain_kernel_gives_the_same_records(dic, config2, tree):
-    """CSC_FLAG_LEAN_COLS (`DeviceBank.lean_cols`): the chain kernel with the column-owner product (a wave per 16-column
-    bank tile against all row tiles, candidates against a running maximum) is kept as a comparison: its trees and MSEs
-    are those of the default chain kernel bit for bit, on config 2, the reference's default tree and a config-4 tree."""
-    if dic.device_bank().fp32_only or not dic.device_bank().lean:
-        pytest.skip("the chain kernels run on the default path only")
-    Kmax, c, B = tree
-    sigs = config2[0][::2] if Kmax == 10 else config2[0]
-    bank = dic.device_bank()
-    out = {}
-    try:
-        for name, cols in (("groups", False), ("cols", True)):
-            bank.lean_cols = cols
-            out[name] = bank.mmpdf_batch(sigs, Kmax, c, B, 0.8, want_coef=False)
-    finally:
-        bank.lean_cols = False
-    a, r = out["cols"], out["groups"]
-    assert np.array_equal(a.node_pos, r.node_pos) and np.array_equal(a.node_atom, r.node_atom)
-    assert np.array_equal(a.node_mse, r.node_mse)
-    assert a.stats[0] == 0 and r.stats[0] == 0
