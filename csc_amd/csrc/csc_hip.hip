@@ -1511,10 +1511,12 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_followup_kernel(const LevelAr
 // VGPRs, no barrier and no LDS traffic for the bank at all --
 //   B fragments   the bank's fp16 blocks are stored fragment-major (one 16-byte piece per lane), so a wave's B fragment
 //                 of (slab, column tile) is ONE global_load_dwordx4 straight from L2 into registers, requested BD = 5
-//                 slabs ahead (a ring of five registers, counted vmcnt waits);
+//                 slabs ahead (a ring of four registers, counted vmcnt waits);
 //   A fragments   the Hankel windows of the residual, from the eight shifted fp16 copies in LDS: a task's slab uses
-//                 window fragments u = 2 s .. 2 s + 7 (row tile mi, slab s -> u = mi + 2 s), ten registers in rotation,
-//                 two new 16-byte LDS reads per slab;
+//                 window fragments u = 2 s .. 2 s + 7 (row tile mi, slab s -> u = mi + 2 s), EIGHT registers in rotation:
+//                 the two fragments a slab uses first (and last: u = 2 s, 2 s + 1) are overwritten, right behind the two
+//                 MFMAs that read them, by the two the NEXT slab uses last (u = 2 s + 8, 2 s + 9) -- two 16-byte LDS
+//                 reads per slab with twelve MFMAs to land under;
 //   per slab      8 MFMAs (v_mfma_f32_16x16x32_f16) on one B fragment.
 // A column tile is multiplied only over ITS live slab range (the bank's columns are sorted by support; outside the
 // range the tile's blocks are zero padding): 101 of 144 (slab, tile) blocks on the canonical bank, where the
@@ -1527,11 +1529,11 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_followup_kernel(const LevelAr
 // products, matrix pipe 98 % full at four workgroups per CU, where the chip holds 1.45 GHz.)
 // A node the fp16 filter cannot settle is flagged (a.flags) and left to mmp_level_followup_kernel (fp32), launched behind.
 #define NG 3                           // (column tiles per group of the large-dictionary kernels below)
-#define BD 5                           // B fragments in flight per wave
+#define BD 4                           // B fragments in flight per wave (= the unroll of the slab loop: 8 window registers / 2)
 #define RAW_CAP 512
-#define TASK_SLOTS 16                  // descriptors per wave: slots 0 .. 14 tasks, slot 15 their number
+#define TASK_SLOTS 8                   // descriptors per wave: slots 0 .. 4 tasks (18 tasks dealt to 4 waves), slot 7 their number
 struct ChainLds {
-    unsigned desc[WG / 64][TASK_SLOTS];   // task = column tile | row half << 4 | first live slab << 8 | one past the last << 16
+    unsigned desc[WG / 64][TASK_SLOTS];   // task = column tile | row half << 4 | first live slab << 5 | one past the last << 10 (16 bits)
     unsigned short range[NT + 1];      // per column tile: first live slab | one past the last << 8
     unsigned gkey;                     // running maximum of the node's filter product (fkey)
     int raw_cnt;
@@ -1578,7 +1580,7 @@ __device__ __forceinline__ void chain_deal_task(ChainLds* cl, int t, int P) {
     }
     const int n = 2 * rank + rh;                                      // task number, longest first
     const int w = (n & 4) ? 3 - (n & 3) : (n & 3);
-    cl->desc[w][n >> 2] = (unsigned)c | ((unsigned)rh << 4) | ((unsigned)lo << 8) | ((unsigned)hi << 16);
+    cl->desc[w][n >> 2] = (unsigned)c | ((unsigned)rh << 4) | ((unsigned)lo << 5) | ((unsigned)hi << 10);
     atomicMax(&cl->desc[w][TASK_SLOTS - 1], (unsigned)(n >> 2) + 1u);
 }
 
@@ -1588,27 +1590,37 @@ __device__ __forceinline__ void chain_deal_task(ChainLds* cl, int t, int P) {
 // No vector-memory operation of this wave may be in flight on entry (the loop's vmcnt counts assume its own loads).
 template <bool FINAL, bool DUMP>
 __device__ __forceinline__ void chain_product16(const _Float16* __restrict__ bank16, const int* perm, ChainLds* cl,
-                                                const _Float16* r16, unsigned mydesc, int nt, int K, int P,
-                                                float band, float tau_fix, float* __restrict__ dump) {
-    const int lane = threadIdx.x & 63;
+                                                const _Float16* r16, unsigned desc01, unsigned desc23, unsigned desc4,
+                                                int nt, int K, int P, float band, float tau_fix, float* __restrict__ dump) {
+    // opaque copies: the descriptors and the lane index are the same on every level of a chain, and the compiler
+    // otherwise hoists the first task's addresses out of the level loop and spills them to scratch
+    asm volatile("" : "+s"(desc01), "+s"(desc23), "+s"(desc4), "+s"(nt));
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
     const int lr = lane & 15, lq = lane >> 4;
     const _Float16* pa0 = r16 + (lr & 7) * R16_CS + (lr & 8) + 8 * lq;       // + 128 row half + 16 u
-    const _Float16* bl = bank16 + lane * 8;
-    f16x8 W[10], Bf[BD];
+    // B addresses: the (uniform) base of the fp16 bank + a 32-bit byte offset per lane
+    const char* bbase = reinterpret_cast<const char*>(bank16);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    unsigned tile_off = 0u;
+    f16x8 W[8], Bf[BD];
     f32x4 acc[8];
     int cur_c = 0, cur_rh = 0, s0 = 0, s1 = 1;
     const _Float16* pa = pa0;
-    const _Float16* bp = bl;
     auto begin_task = [&](int it) __attribute__((always_inline)) {
-        const unsigned d = (unsigned)__builtin_amdgcn_readlane((int)mydesc, it);
-        cur_c = (int)(d & 15u); cur_rh = (int)((d >> 4) & 1u); s0 = (int)((d >> 8) & 255u); s1 = (int)((d >> 16) & 255u);
+        // the wave's descriptors ride in scalar registers (16 bits each; a VGPR copy was spilled and re-loaded here,
+        // and the wait for that re-load also waited for the B fragments just requested)
+        const unsigned dw = it < 2 ? desc01 : (it < 4 ? desc23 : desc4);
+        const unsigned d = (it & 1) && it < 4 ? dw >> 16 : dw & 0xffffu;
+        cur_c = (int)(d & 15u); cur_rh = (int)((d >> 4) & 1u); s0 = (int)((d >> 5) & 31u); s1 = (int)((d >> 10) & 31u);
         pa = pa0 + 128 * cur_rh;
-        bp = bl + cur_c * BLKF;
+        tile_off = (unsigned)cur_c * (BLKF * 2u);
 #pragma unroll
         for (int i = 0; i < 8; ++i) W[i] = *reinterpret_cast<const f16x8*>(pa + 16 * (2 * s0 + i));
         // (a task shorter than BD slabs re-loads its last one: the load count stays fixed)
 #pragma unroll
-        for (int q = 0; q < BD; ++q) Bf[q] = *reinterpret_cast<const f16x8*>(bp + min(s0 + q, s1 - 1) * SLABF);
+        for (int q = 0; q < BD; ++q)
+            Bf[q] = *reinterpret_cast<const f16x8*>(bbase + (tile_off + (unsigned)min(s0 + q, s1 - 1) * (SLABF * 2u)) + lane16);
     };
     // LDS byte offset of the running maximum (for the hand-written ds_max_u32 below)
     const unsigned key_off = (unsigned)(size_t)(lptr_t)&cl->gkey;
@@ -1693,21 +1705,31 @@ __device__ __forceinline__ void chain_product16(const _Float16* __restrict__ ban
         auto step = [&](auto phc, auto firstc) __attribute__((always_inline)) {
             constexpr int PH = decltype(phc)::value;
             constexpr bool FIRST = decltype(firstc)::value;
-            W[(2 * PH + 8) % 10] = *reinterpret_cast<const f16x8*>(pa + 16 * (2 * s + 8));
-            W[(2 * PH + 9) % 10] = *reinterpret_cast<const f16x8*>(pa + 16 * (2 * s + 9));
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
-                acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[(2 * PH + mi) % 10], Bf[PH],
-                                                                 FIRST ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mi], 0, 0, 0);
-            // the fragment BD slabs ahead; past the task's end the SAME number of loads goes out (the vmcnt counts are
-            // static), every lane reading one 16-byte piece: one cache line for the wave instead of eight
-            if (s + BD <= sl) Bf[PH] = *reinterpret_cast<const f16x8*>(bp + (s + BD) * SLABF);
-            else Bf[PH] = *reinterpret_cast<const f16x8*>(bank16);
+            for (int mi = 0; mi < 2; ++mi)
+                acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[(2 * PH + mi) % 8], Bf[PH], FIRST ? zero : acc[mi], 0, 0, 0);
+            // the next slab's last two fragments, into the registers those two MFMAs have just read
+            W[(2 * PH) % 8] = *reinterpret_cast<const f16x8*>(pa + 16 * (2 * s + 8));
+            W[(2 * PH + 1) % 8] = *reinterpret_cast<const f16x8*>(pa + 16 * (2 * s + 9));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 2; mi < 8; ++mi)
+                acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[(2 * PH + mi) % 8], Bf[PH], FIRST ? zero : acc[mi], 0, 0, 0);
+            // The fragment BD slabs ahead.  Past the task's end the SAME number of loads goes out (the vmcnt counts are
+            // static), every lane reading ONE 16-byte piece: one cache line for the wave instead of eight.
+            {
+                // (uniform base in scalar registers + the lane's fixed 32-bit offset: no vector ALU work for the address
+                // and no address temporaries -- the allocator had put those into ring registers with loads in flight)
+                const bool more = s + BD <= sl;
+                const char* sb = bbase + (more ? tile_off + (unsigned)(s + BD) * (SLABF * 2u) : 0u);
+                Bf[PH] = *reinterpret_cast<const f16x8*>(sb + (more ? lane16 : 0u));
+            }
             ++s;
             __builtin_amdgcn_sched_barrier(0);
         };
         step(std::integral_constant<int, 0>{}, std::true_type{});
-        // whole rounds of five slabs in a loop with ONE way round (a `break` inside the round lets the compiler merge
+        // whole rounds of four slabs in a loop with ONE way round (a `break` inside the round lets the compiler merge
         // the exits' load states into the loop header: a full vmcnt(0) drain every round), then the rest
         const int nrest = s1 - s;
         const int rounds = nrest / BD, rem = nrest - rounds * BD;
@@ -1715,17 +1737,13 @@ __device__ __forceinline__ void chain_product16(const _Float16* __restrict__ ban
             step(std::integral_constant<int, 1>{}, std::false_type{});
             step(std::integral_constant<int, 2>{}, std::false_type{});
             step(std::integral_constant<int, 3>{}, std::false_type{});
-            step(std::integral_constant<int, 4>{}, std::false_type{});
             step(std::integral_constant<int, 0>{}, std::false_type{});
         }
         if (rem >= 1) {
             step(std::integral_constant<int, 1>{}, std::false_type{});
             if (rem >= 2) {
                 step(std::integral_constant<int, 2>{}, std::false_type{});
-                if (rem >= 3) {
-                    step(std::integral_constant<int, 3>{}, std::false_type{});
-                    if (rem >= 4) step(std::integral_constant<int, 4>{}, std::false_type{});
-                }
+                if (rem >= 3) step(std::integral_constant<int, 3>{}, std::false_type{});
             }
         }
         const int done_c = cur_c, done_rh = cur_rh;
@@ -1787,8 +1805,10 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
     const float band = 2.f * ((9.765625e-04f + DELTA_REL + 1e-6f) * am + 2.9802322e-08f * sqrtf((float)L) * (1.f + am));
     if (tid == 0) a.flags[s * Fd + j] = 0;
     __syncthreads();                                                  // the task table
-    // the wave's task descriptors ride in a register: lane i holds descriptor i
-    const unsigned mydesc = cl->desc[wave][lane & (TASK_SLOTS - 1)];
+    // the wave's task descriptors, packed into scalar registers
+    const unsigned desc01 = (unsigned)__builtin_amdgcn_readfirstlane((int)(cl->desc[wave][0] | (cl->desc[wave][1] << 16)));
+    const unsigned desc23 = (unsigned)__builtin_amdgcn_readfirstlane((int)(cl->desc[wave][2] | (cl->desc[wave][3] << 16)));
+    const unsigned desc4 = (unsigned)__builtin_amdgcn_readfirstlane((int)cl->desc[wave][4]);
     const int nt = __builtin_amdgcn_readfirstlane((int)cl->desc[wave][TASK_SLOTS - 1]);
 
     // The chain cannot go on in fp16 at level d: the node's state goes to its workspace row (level d0's is still
@@ -1831,7 +1851,7 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
         const unsigned trace_t0 = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
         // ---- ONE sweep; every task's candidates against the running maximum ------------------------------------------
-        chain_product16<false, false>(a.bank16, sl->perm, cl, r16, mydesc, nt, K, a.P, band, 0.f, nullptr);
+        chain_product16<false, false>(a.bank16, sl->perm, cl, r16, desc01, desc23, desc4, nt, K, a.P, band, 0.f, nullptr);
         __syncthreads();
         PROF_MARK(1);
 #ifdef CSC_PHASE_PROF
@@ -1852,7 +1872,7 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
             __syncthreads();
             if (tid == 0) cl->raw_cnt = 0;
             __syncthreads();
-            chain_product16<true, false>(a.bank16, sl->perm, cl, r16, mydesc, nt, K, a.P, band, tau, nullptr);
+            chain_product16<true, false>(a.bank16, sl->perm, cl, r16, desc01, desc23, desc4, nt, K, a.P, band, tau, nullptr);
             __syncthreads();
             nraw = cl->raw_cnt;
             if (nraw > RAW_CAP) { give_up(d); return; }               // a flat residual: fp32
@@ -1907,7 +1927,7 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
     PROF_MARK(9);
 }
 
-__global__ __launch_bounds__(WG, 4) void mmp_level_lean_kernel(const LevelArgs a) { lean_chain(a); }
+__global__ __launch_bounds__(WG, 5) void mmp_level_lean_kernel(const LevelArgs a) { lean_chain(a); }
 
 // ------------------------------------------------------------------------------------------------
 // test aid: the fp16 filter product itself (what the level kernels only ever hold in registers)
@@ -1987,10 +2007,12 @@ __global__ __launch_bounds__(WG, 2) void filter_product_kernel(const _Float16* _
             if (!live && k >= 0)
                 for (int p = tid >> 4; p < P; p += WG / 16) out[(b * P + p) * K + k] = 0.f;
         }
-        const unsigned mydesc = cls.desc[wave][lane & (TASK_SLOTS - 1)];
+        const unsigned desc01 = (unsigned)__builtin_amdgcn_readfirstlane((int)(cls.desc[wave][0] | (cls.desc[wave][1] << 16)));
+        const unsigned desc23 = (unsigned)__builtin_amdgcn_readfirstlane((int)(cls.desc[wave][2] | (cls.desc[wave][3] << 16)));
+        const unsigned desc4 = (unsigned)__builtin_amdgcn_readfirstlane((int)cls.desc[wave][4]);
         const int nt = __builtin_amdgcn_readfirstlane((int)cls.desc[wave][TASK_SLOTS - 1]);
         WAIT_VM(0);
-        chain_product16<true, true>(bank16, perm, &cls, r16, mydesc, nt, K, P, 0.f, INFINITY, out + b * (size_t)P * K);
+        chain_product16<true, true>(bank16, perm, &cls, r16, desc01, desc23, desc4, nt, K, P, 0.f, INFINITY, out + b * (size_t)P * K);
     }
 }
 

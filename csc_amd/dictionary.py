@@ -361,7 +361,7 @@ class CSCDictionary:
     # batched engine front-ends
     # ------------------------------------------------------------------------------------------
     def _records(self, signals, max_sparsity, connections, branches, dissimilarity, want_coef=False,
-                 fields="rec", sharded=False, presharded=False, shard_sizes=None, recv=None):
+                 fields="rec", sharded=False, presharded=False, shard_sizes=None, recv=None, async_gather=False):
         """The device-level core of every batched front-end: signals [S, N] (host array or device tensor) ->
         ([S, width] uint8 per-signal records ON THE DEVICE, stats tensor), layout BatchResult.field_specs.
 
@@ -369,7 +369,8 @@ class CSCDictionary:
         the batch on its own GPU (chunks of PIPELINE_CHUNK signals) and the records are gathered ONCE,
         device to device, on rank 0; the other ranks get (None, stats).  Replaces joblib.Parallel
         (reference :1147).  ``presharded=True``: ``signals`` already is this rank's shard (``shard_sizes``:
-        every rank's shard length; found with one all_gather when not given)."""
+        every rank's shard length; found with one all_gather when not given).  ``async_gather=True``: the
+        gather is only enqueued and a ``distributed.PendingRows`` comes back in place of the rows (``wait()``)."""
         import torch
         from . import distributed as D
         from .engine import BatchResult
@@ -403,10 +404,10 @@ class CSCDictionary:
             stats = torch.zeros(4, dtype=torch.int32)
         local = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
         if not dist_on:
-            return local, stats
+            return (D.PendingRows(None, [local], None, [local.shape[0]], True) if async_gather else local), stats
         if torch.distributed.get_backend() != "nccl":
             local = local.cpu()
-        return D.gather_rows(local, shard_sizes, out=recv), stats
+        return D.gather_rows(local, shard_sizes, out=recv, async_op=async_gather), stats
 
     def _batch(self, signals, max_sparsity, connections, branches, dissimilarity, want_coef=False,
                sharded=False, fields="all"):
@@ -680,14 +681,16 @@ class CSCDictionary:
 
     def mmpdfSparVarRecords(self, signals, connections_level: int = 3, dissimilarity: float = 0.8,
                             nb_branches: int = 10, max_sparsity: int = 10, sharded: bool = False,
-                            presharded: bool = False, shard_sizes=None, recv=None):
+                            presharded: bool = False, shard_sizes=None, recv=None, async_gather: bool = False):
         """Device-in / device-out form of mmpdfSparVarBatch: ``signals`` may be a float64 tensor already in
         HBM; returns the [S, (16 + 8 K) K] uint8 sparVar records (K f64 mse | K x 2 i32 leaf | K x K x 2 i32
         (pos, atom) per signal, BatchResult.field_specs(fields="rec")) as a tensor on this process's GPU --
         after the one gather on rank 0, None on the other ranks, when ``sharded`` under torch.distributed.
-        Nothing passes through the host.  ``SparVarBatch.from_records`` turns the tensor into results."""
+        Nothing passes through the host.  ``SparVarBatch.from_records`` turns the tensor into results.
+        ``async_gather=True`` returns a ``distributed.PendingRows`` at once (the gather enqueued, the next batch's
+        solve free to run under it); its ``wait()`` gives the rows."""
         rows, _ = self._records(signals, max_sparsity, connections_level, nb_branches, dissimilarity, False, "rec",
-                                sharded, presharded, shard_sizes, recv)
+                                sharded, presharded, shard_sizes, recv, async_gather)
         return rows
 
     # ------------------------------------------------------------------------------------------

@@ -86,17 +86,43 @@ def shard_sizes(n: int, world: int):
     return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
 
 
-def gather_rows(local: torch.Tensor, sizes, dst: int = 0, out=None):
+class PendingRows:
+    """A gather in flight (``gather_rows(..., async_op=True)``): ``wait()`` makes the current stream wait for the
+    collective and returns what ``gather_rows`` returns.  The send / receive buffers stay referenced until then."""
+
+    def __init__(self, work, recv, send, sizes, dst_is_me):
+        self._work, self._recv, self._send, self._sizes, self._me = work, recv, send, sizes, dst_is_me
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        self._send = None
+        if not self._me:
+            return None
+        return _assemble(self._recv, self._sizes)
+
+
+def _assemble(recv, sizes):
+    cap, R = max(sizes), len(sizes)
+    if all(n == cap for n in sizes):
+        return torch.cat(recv, dim=0) if R > 1 else recv[0]
+    return torch.cat([recv[q][:sizes[q]] for q in range(R)], dim=0)
+
+
+def gather_rows(local: torch.Tensor, sizes, dst: int = 0, out=None, async_op: bool = False):
     """THE collective of the path.  ``local``: this rank's [sizes[rank], width] uint8 rows, in input order, on
     this rank's GPU (nccl) or on the host (gloo).  Returns the [sum(sizes), width] tensor on rank ``dst`` (same
     device kind), None elsewhere.  Shards are padded to the largest so that one equal-size ``dist.gather``
     does it; ``out`` (rank dst: a list of world [cap, width] buffers) lets a caller reuse the receive
     buffers from call to call -- the result is then assembled from those buffers and, with one rank, IS
-    ``out[0]`` (no copy): the next call with the same ``out`` overwrites it, so consume or clone it first."""
+    ``out[0]`` (no copy): the next call with the same ``out`` overwrites it, so consume or clone it first.
+    ``async_op=True``: the collective is only enqueued (the solve of the next batch can run under it) and a
+    ``PendingRows`` is returned; its ``wait()`` gives the rows."""
     assert local.dtype == torch.uint8 and local.dim() == 2
     if not is_distributed():
         assert local.shape[0] == sum(sizes)
-        return local
+        return PendingRows(None, [local], None, [local.shape[0]], True) if async_op else local
     R, r = world_size(), rank()
     assert len(sizes) == R and local.shape[0] == sizes[r], (tuple(local.shape), sizes, r)
     _check_one_rank_per_device(local.device)
@@ -109,12 +135,12 @@ def gather_rows(local: torch.Tensor, sizes, dst: int = 0, out=None):
     recv = None
     if r == dst:
         recv = out if out is not None else [torch.empty_like(send) for _ in range(R)]
-    dist.gather(send, recv, dst=dst)
+    work = dist.gather(send, recv, dst=dst, async_op=async_op)
+    if async_op:
+        return PendingRows(work, recv, send, list(sizes), r == dst)
     if r != dst:
         return None
-    if all(n == cap for n in sizes):
-        return torch.cat(recv, dim=0) if R > 1 else recv[0]
-    return torch.cat([recv[q][:sizes[q]] for q in range(R)], dim=0)
+    return _assemble(recv, sizes)
 
 
 def gather_records(local: np.ndarray, total: int, dst: int = 0, device=None):
