@@ -1535,6 +1535,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_followup_kernel(const LevelAr
 struct ChainLds {
     unsigned desc[WG / 64][TASK_SLOTS];   // task = column tile | row half << 4 | first live slab << 5 | one past the last << 10 (16 bits)
     unsigned short range[NT + 1];      // per column tile: first live slab | one past the last << 8
+    int zero_atoms;                    // an all-zero column tile holds a real atom (no task computes it)
     unsigned gkey;                     // running maximum of the node's filter product (fkey)
     int raw_cnt;
     int raw_idx[RAW_CAP];
@@ -1567,18 +1568,30 @@ __device__ __forceinline__ void chain_tile_range(const int32_t* __restrict__ met
         if (((uint32_t)meta[CSC_TILE_COLS + q] >> c) & 1u) { lo = min(lo, q); hi = q + 1; }
     cl->range[c] = (unsigned short)(min(lo, hi) | (hi << 8));
     if (c < WG / 64) cl->desc[c][TASK_SLOTS - 1] = 0u;                  // the waves' task counts, raised below
+    if (c == 0) cl->zero_atoms = 0;
 }
-__device__ __forceinline__ void chain_deal_task(ChainLds* cl, int t, int P) {
+__device__ __forceinline__ void chain_deal_task(ChainLds* cl, const int* perm, int t, int P) {
     const int c = t >> 1, rh = t & 1;
     const int pk = cl->range[c], lo = pk & 0xff, hi = pk >> 8, len = hi - lo;
-    if (len <= 0 || 128 * rh >= P) return;
+    if (len <= 0) {
+        // an all-zero column tile has no task; should it hold a real atom (an all-zero atom: its correlations are
+        // exact zeros and may win when everything else is negative) the chain is left to the fp32 kernels
+        if (rh == 0) {
+            bool real = false;
+            for (int q = 0; q < 16; ++q) real |= perm[16 * c + q] >= 0;
+            if (real) cl->zero_atoms = 1;
+        }
+        return;
+    }
+    if (128 * rh >= P) return;
     int rank = 0;
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
         const int pq = cl->range[q], lq = (pq >> 8) - (pq & 0xff);
         rank += (lq > len || (lq == len && q < c)) ? 1 : 0;
     }
-    const int n = 2 * rank + rh;                                      // task number, longest first
+    const int n = (P > 128 ? 2 * rank + rh : rank);                   // task number, longest first (no gaps: a wave
+                                                                      // runs slots 0 .. count - 1)
     const int w = (n & 4) ? 3 - (n & 3) : (n & 3);
     cl->desc[w][n >> 2] = (unsigned)c | ((unsigned)rh << 4) | ((unsigned)lo << 5) | ((unsigned)hi << 10);
     atomicMax(&cl->desc[w][TASK_SLOTS - 1], (unsigned)(n >> 2) + 1u);
@@ -1591,7 +1604,8 @@ __device__ __forceinline__ void chain_deal_task(ChainLds* cl, int t, int P) {
 template <bool FINAL, bool DUMP>
 __device__ __forceinline__ void chain_product16(const _Float16* __restrict__ bank16, const int* perm, ChainLds* cl,
                                                 const _Float16* r16, unsigned desc01, unsigned desc23, unsigned desc4,
-                                                int nt, int K, int P, float band, float tau_fix, float* __restrict__ dump) {
+                                                int nt, int nslab, int K, int P, float band, float tau_fix,
+                                                float* __restrict__ dump) {
     // opaque copies: the descriptors and the lane index are the same on every level of a chain, and the compiler
     // otherwise hoists the first task's addresses out of the level loop and spills them to scratch
     asm volatile("" : "+s"(desc01), "+s"(desc23), "+s"(desc4), "+s"(nt));
@@ -1613,6 +1627,8 @@ __device__ __forceinline__ void chain_product16(const _Float16* __restrict__ ban
         const unsigned dw = it < 2 ? desc01 : (it < 4 ? desc23 : desc4);
         const unsigned d = (it & 1) && it < 4 ? dw >> 16 : dw & 0xffffu;
         cur_c = (int)(d & 15u); cur_rh = (int)((d >> 4) & 1u); s0 = (int)((d >> 5) & 31u); s1 = (int)((d >> 10) & 31u);
+        // (whatever a descriptor holds, the addresses below stay inside the bank and the window copies)
+        cur_c = min(cur_c, NT - 1); s1 = max(1, min(s1, min(nslab, 16))); s0 = min(s0, s1 - 1);
         pa = pa0 + 128 * cur_rh;
         tile_off = (unsigned)cur_c * (BLKF * 2u);
 #pragma unroll
@@ -1689,6 +1705,7 @@ __device__ __forceinline__ void chain_product16(const _Float16* __restrict__ ban
             }
         }
     };
+    nt = min(nt, 5);
     if (nt <= 0) return;
 #ifdef CSC_PHASE_PROF
     // (two stamps per product only: a stamp is an s_memtime + a full LDS-counter wait, three per task distorted the loop)
@@ -1783,7 +1800,7 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
     const double* rin = (d0 == 0 || a.from_root) ? a.signals + s * (size_t)N : a.ws[d0 & 1] + (s * Fd + j) * (size_t)a.NS;
     double rnorm2, first[4];
     node_prologue(a, sl, r64, nullptr, Npad, 0, rin, s, j, rnorm2, first, a.from_root ? 0 : d0);
-    if (tid >= 64 && tid < 64 + 2 * NT) chain_deal_task(cl, tid - 64, a.P);   // (behind the prologue's barrier)
+    if (tid >= 64 && tid < 64 + 2 * NT) chain_deal_task(cl, sl->perm, tid - 64, a.P);   // (behind the prologue's barrier)
     if (a.from_root) {
         // d0 = 1 and the root level left only its pick: this node is the signal's child (pos, atom) with <atom, signal>
         // parked in its MSE slot.  Its least squares, residual, factor and MSE are child_solve_and_write's at depth 0,
@@ -1827,9 +1844,10 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
 
     // ---- the chain: this node, its child, its grandchild ... down to the leaves; the residual, the Cholesky
     // factor and the coefficients stay in LDS from one level to the next, only the node tables go to HBM
+    const bool zero_atoms = cl->zero_atoms != 0;                      // (uniform; read behind the task table's barrier)
     for (int d = d0; d < a.Kmax; ++d) {
-        // NaN / Inf / extreme scales: fp32
-        if (!(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 1e-30 && rnorm2 < 1e30)) { give_up(d); return; }
+        // NaN / Inf / extreme scales, an all-zero atom: fp32
+        if (zero_atoms || !(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 1e-30 && rnorm2 < 1e30)) { give_up(d); return; }
         {
             // the window elements build_r16 wants in registers, from the LDS copy on every level (carried from the
             // prologue in registers they lived in scratch across the level loop)
@@ -1851,7 +1869,7 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
         const unsigned trace_t0 = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
         // ---- ONE sweep; every task's candidates against the running maximum ------------------------------------------
-        chain_product16<false, false>(a.bank16, sl->perm, cl, r16, desc01, desc23, desc4, nt, K, a.P, band, 0.f, nullptr);
+        chain_product16<false, false>(a.bank16, sl->perm, cl, r16, desc01, desc23, desc4, nt, nslab, K, a.P, band, 0.f, nullptr);
         __syncthreads();
         PROF_MARK(1);
 #ifdef CSC_PHASE_PROF
@@ -1872,7 +1890,7 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
             __syncthreads();
             if (tid == 0) cl->raw_cnt = 0;
             __syncthreads();
-            chain_product16<true, false>(a.bank16, sl->perm, cl, r16, desc01, desc23, desc4, nt, K, a.P, band, tau, nullptr);
+            chain_product16<true, false>(a.bank16, sl->perm, cl, r16, desc01, desc23, desc4, nt, nslab, K, a.P, band, tau, nullptr);
             __syncthreads();
             nraw = cl->raw_cnt;
             if (nraw > RAW_CAP) { give_up(d); return; }               // a flat residual: fp32
@@ -1975,7 +1993,7 @@ __global__ __launch_bounds__(WG, 2) void filter_product_kernel(const _Float16* _
     if (tid >= 160 && tid < 160 + NT) chain_tile_range(meta, nslab, &cls, tid - 160);
     if (tid == 0) { cls.raw_cnt = 0; cls.gkey = fkey(-INFINITY); }
     __syncthreads();
-    if (tid >= 64 && tid < 64 + 2 * NT) chain_deal_task(&cls, tid - 64, P);
+    if (tid >= 64 && tid < 64 + 2 * NT) chain_deal_task(&cls, perm, tid - 64, P);
     const float am = sqrtf(*amax2);
     if (tid == 0) {
         eps[b] = (9.765625e-04f + DELTA_REL + 1e-6f) * am + 2.9802322e-08f * sqrtf((float)L) * (1.f + am);
@@ -2012,7 +2030,7 @@ __global__ __launch_bounds__(WG, 2) void filter_product_kernel(const _Float16* _
         const unsigned desc4 = (unsigned)__builtin_amdgcn_readfirstlane((int)cls.desc[wave][4]);
         const int nt = __builtin_amdgcn_readfirstlane((int)cls.desc[wave][TASK_SLOTS - 1]);
         WAIT_VM(0);
-        chain_product16<true, true>(bank16, perm, &cls, r16, desc01, desc23, desc4, nt, K, P, 0.f, INFINITY, out + b * (size_t)P * K);
+        chain_product16<true, true>(bank16, perm, &cls, r16, desc01, desc23, desc4, nt, nslab, K, P, 0.f, INFINITY, out + b * (size_t)P * K);
     }
 }
 
