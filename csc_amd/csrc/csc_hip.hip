@@ -78,6 +78,16 @@ __device__ unsigned g_trace_n;
 #define T3_STAMP(i)
 #endif
 
+// Development aid (make candcheck): the chain kernel built with a forced publication order of the running maximum
+// (CSC_CAND_ORDER 0 = as shipped, 1 = loosest: a task's threshold sees only the task's own maximum, 2 = tightest: every
+// task sees the final maximum, i.e. the second pass is forced) and a dump of every node's raw count and final candidate
+// list, for tests/test_gpu_cand_order.py.
+#ifdef CSC_CAND_ORDER
+#define CAND_DUMP_NODES 16384
+#define CAND_DUMP_W 260                 // raw count | final count | up to 256 indices | spare
+__device__ int g_cand_dump[CAND_DUMP_NODES][CAND_DUMP_W];
+#endif
+
 static thread_local char g_err[256] = "";
 #define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
 
@@ -1682,6 +1692,12 @@ __device__ __forceinline__ void chain_product16(const _Float16* __restrict__ ban
             asm volatile("ds_max_u32 %1, %2\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
                          : "=v"(cur) : "v"(key_off), "v"(fkey(lmax)) : "memory");
             thr = fkey_inv(cur) - band;
+#if defined(CSC_CAND_ORDER) && CSC_CAND_ORDER == 1
+            {   // loosest order: nothing of the other tasks has been published yet
+                const float bm = wave_max(lmax);
+                thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bm == bm ? bm : INFINITY), 63)) - band;
+            }
+#endif
         }
         if (lmax >= thr) {
             uint32_t mk = 0u;
@@ -1885,7 +1901,13 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
 #endif
         int nraw = cl->raw_cnt;
         const float tau = fkey_inv(cl->gkey) - band;
-        if (nraw > RAW_CAP) {
+#if defined(CSC_CAND_ORDER) && CSC_CAND_ORDER == 2
+        const bool force_final = true;                                // tightest order: every task sees the final maximum
+#else
+        const bool force_final = false;
+#endif
+        const int nraw_first = nraw;
+        if (nraw > RAW_CAP || force_final) {
             // (uniform, rare) the early thresholds let too many entries through: once more, with the final band
             __syncthreads();
             if (tid == 0) cl->raw_cnt = 0;
@@ -1909,6 +1931,17 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
         __syncthreads();
         PROF_MARK(3);
         const int ncand_raw = sl->cand_cnt;
+#ifdef CSC_CAND_ORDER
+        {
+            const size_t node = ((size_t)s * Fd + j) * a.Kmax + d;
+            if (node < CAND_DUMP_NODES) {
+                if (tid == 0) { g_cand_dump[node][0] = force_final ? nraw : nraw_first; g_cand_dump[node][1] = ncand_raw; }
+                for (int i = tid; i < min(ncand_raw, 2 * CAND_CAP); i += WG)
+                    g_cand_dump[node][2 + i] = i < CAND_CAP ? sl->cand_idx[i] : reinterpret_cast<const int*>(sl->cand_val)[i - CAND_CAP];
+            }
+        }
+        __syncthreads();
+#endif
         if (ncand_raw > 2 * CAND_CAP) { give_up(d); return; }         // too many entries in the fp16 band: fp32
         if (ncand_raw <= CAND_CAP) {
             rescore_and_choose(a, sl, r64, ncand_raw, false, d);
@@ -3911,6 +3944,21 @@ int csc_timer_read(csc_timer* t, float* ms, int* tag, int n) {
     }
     return m;
 }
+
+#ifdef CSC_CAND_ORDER
+// the dump of the chain kernel's candidate lists: rows [0, nodes) of g_cand_dump -> out (nodes x CAND_DUMP_W ints);
+// the dump is cleared to -1 afterwards (call once before the first run)
+int csc_dbg_cand_read(int* out, int nodes) {
+    hipDeviceSynchronize();
+    if (nodes > CAND_DUMP_NODES) nodes = CAND_DUMP_NODES;
+    if (nodes > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cand_dump), (size_t)nodes * CAND_DUMP_W * sizeof(int)) != hipSuccess) return -1;
+    void* p = nullptr;                                                // every row back to "not written" (-1)
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_cand_dump)) != hipSuccess || hipMemset(p, 0xff, sizeof(int) * CAND_DUMP_NODES * CAND_DUMP_W) != hipSuccess) return -1;
+    hipDeviceSynchronize();
+    return nodes;
+}
+int csc_dbg_cand_width(void) { return CAND_DUMP_W; }
+#endif
 
 #ifdef CSC_PHASE_PROF
 int csc_prof_read(unsigned long long* out32, int reset) {
