@@ -3570,8 +3570,16 @@ int csc_sim_words(int N, int L) {
     return 2 * ((2 * P - 1 + 63) / 64);
 }
 
+static int scratch_ptr(void** out);                                 // csc_static_scratch.inc
+
 int csc_bank_pack(const double* d_bank64, int K, int L, float* d_bank32t, void* stream) {
     if (!d_bank64 || !d_bank32t || K <= 0 || L <= 0) FAIL(-1, "csc_bank_pack: bad arguments");
+    {   // this is the library's set-up call on a device: look the static scratch of csc_mmpdf_batch_static up now, so
+        // that the entry point itself never has to (it may run under stream capture)
+        void* p = nullptr;
+        const int rc = scratch_ptr(&p);
+        if (rc) return rc;
+    }
     if (n_slabs(L) > MAX_SLABS) FAIL(-8, "atom length %d exceeds %d", L, MAX_SLABS * SLAB);
     const size_t total = tile_floats(K, L);
     const int ntile = n_tiles(K), nslab = n_slabs(L), npad = ntile * CSC_TILE_COLS - K;

@@ -139,7 +139,12 @@ int csc_mmpdf_batch(const float* d_bank32t, const double* d_bank64, const uint32
  * on holds until the process ends.  The call allocates and frees nothing (no hipMalloc / hipFree, no library
  * allocator); a batch whose csc_mmpdf_workspace_bytes(...) exceeds the array is refused with -10 (config 2:
  * up to 1844 signals per call).  Every call on one GPU shares that GPU's array: calls that overlap on one GPU
- * (two streams, two host threads) race -- serialise them or use csc_mmpdf_batch with separate workspaces.
+ * (two streams, two host threads) race -- serialise them or use csc_mmpdf_batch with separate workspaces; the
+ * library keeps no busy flag (it could not see a captured graph's replays).  The array costs 64 MiB of HBM on every
+ * GPU the process touches through this library, used or not.  Its device address is looked up by csc_bank_pack (the
+ * set-up call) -- or by the first call, if no bank was packed on that device -- so a call under stream capture
+ * issues launches and one memset only: tests/test_zz_no_alloc.py captures a batch into a HIP graph after one
+ * ordinary call (which loads the code objects and sets the kernels' LDS attributes) and replays it on new signals.
  * csc_static_scratch_bytes() returns the array's size. */
 size_t csc_static_scratch_bytes(void);
 int csc_mmpdf_batch_static(const float* d_bank32t, const double* d_bank64, const uint32_t* d_sim_bits,

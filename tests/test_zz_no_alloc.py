@@ -100,3 +100,49 @@ def test_static_scratch_entry_beyond_one_register_tile():
         b = bank.mmpdf_launch(sig, 4, 3, 10, 0.7, want_coef=True)
         for name in NAMES:
             assert torch.equal(a[name], b[name]), (name, n)
+
+
+def test_static_scratch_entry_under_stream_capture(golden_signals):
+    """What the entry point is for: the whole tree search of a batch captured ONCE into a HIP graph (no allocation, no
+    synchronisation, no host read-back inside the call) and replayed on new signals -- node tables and records equal to
+    csc_mmpdf_batch's on both replays."""
+    import torch
+    import csc_amd
+    from csc_amd import _lib
+    d = csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.005), np.arange(0.010, 0.036, 0.002), [1])
+    bank = d.device_bank()
+    lib, dev = bank.lib, bank.device
+    sigs = golden_signals["signals"]
+    first = torch.from_numpy(np.concatenate([sigs, sigs[::-1] * 0.5])).to(dev)                 # 128 signals
+    second = torch.from_numpy(np.concatenate([sigs * 3.0, sigs[::-1]])).to(dev)
+    K, c, B = 5, 3, 3
+    S, N = first.shape
+    _, NN = _lib.tree_shape(K, c, B)
+    sig = torch.zeros_like(first)
+    mine = {"node_pos": torch.zeros((S, NN), dtype=torch.int32, device=dev),
+            "node_atom": torch.zeros((S, NN), dtype=torch.int32, device=dev),
+            "node_mse": torch.zeros((S, NN), dtype=torch.float64, device=dev),
+            "node_coef": torch.zeros((S, NN, K), dtype=torch.float64, device=dev),
+            "rec_buf": torch.zeros((S, K * (16 + 8 * K)), dtype=torch.uint8, device=dev),
+            "stats": torch.zeros(4, dtype=torch.int32, device=dev)}
+    sim = bank.similarity_table(N, 0.8)
+    bank.mmpdf_launch(first[:8], K, c, B, 0.8, want_coef=True, static_scratch=True)            # modules loaded, attributes set
+    torch.cuda.synchronize(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        mine["stats"].zero_()
+        rc = lib.csc_mmpdf_batch_static(_ptr(bank.bank32t), _ptr(bank.bank64), _ptr(sim), bank.K, bank.L, _ptr(sig), S, N,
+                                        K, c, B, 4, _ptr(mine["node_pos"]), _ptr(mine["node_atom"]),
+                                        _ptr(mine["node_mse"]), _ptr(mine["node_coef"]), _ptr(mine["rec_buf"]), None,
+                                        None, _ptr(mine["stats"]), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    _lib.check(rc, "csc_mmpdf_batch_static under capture")
+    for data in (first, second):
+        sig.copy_(data)
+        for n in NAMES[:-1]:
+            mine[n].fill_(0)
+        graph.replay()
+        torch.cuda.synchronize(dev)
+        ref = bank.mmpdf_launch(data, K, c, B, 0.8, want_coef=True)
+        for n in NAMES[:-1]:
+            assert torch.equal(mine[n], ref[n]), n
+        assert torch.equal(mine["stats"][[0, 1, 3]], ref["stats"][[0, 1, 3]])
