@@ -1068,8 +1068,8 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
         for (int i = 0; i < d; ++i) {
             const double dg = sl->Lf[TRI(i) + i];
             double v = sl->g[i];
-            for (int m = 0; m < i; ++m) v -= sl->Lf[TRI(i) + m] * sl->y[m];
-            v = (dg != 0.0) ? v / dg : 0.0;
+            for (int m = 0; m < i; ++m) v = fma(-sl->Lf[TRI(i) + m], sl->y[m], v);
+            v = (dg != 0.0) ? v * (1.0 / dg) : 0.0;                 // (reciprocal first: bit for bit chain_tail_fast's stored 1 / l_ii)
             sl->y[i] = v;
             yy = fma(v, v, yy);
         }
@@ -1089,8 +1089,8 @@ __device__ __forceinline__ void child_solve_and_write(const LevelArgs& a, NodeLd
         for (int r = d - 1; r >= 0; --r) {
             const double dg = sl->Lf[TRI(r) + r];
             double v = -sl->y[r] * xd;
-            for (int m = r + 1; m < d; ++m) v -= sl->Lf[TRI(m) + r] * sl->x[m];
-            sl->x[r] = (dg != 0.0) ? v / dg : 0.0;
+            for (int m = r + 1; m < d; ++m) v = fma(-sl->Lf[TRI(m) + r], sl->x[m], v);
+            sl->x[r] = (dg != 0.0) ? v * (1.0 / dg) : 0.0;
         }
         if (bad && a.stats) atomicAdd(&a.stats[1], 1);
     }
@@ -1550,6 +1550,7 @@ struct ChainLds {
     int raw_cnt;
     int raw_idx[RAW_CAP];
     float raw_val[RAW_CAP];
+    double Linv[KMAX];                 // 1 / diagonal of the Cholesky factor (0 for a dead column): chain_tail_fast's solve
 };
 
 // float <-> unsigned key with the same order (for LDS atomicMax on maxima)
@@ -1619,6 +1620,10 @@ __device__ __forceinline__ void chain_product16(const _Float16* __restrict__ ban
     // opaque copies: the descriptors and the lane index are the same on every level of a chain, and the compiler
     // otherwise hoists the first task's addresses out of the level loop and spills them to scratch
     asm volatile("" : "+s"(desc01), "+s"(desc23), "+s"(desc4), "+s"(nt));
+    // (uniform values the epilogues use, pinned to scalar registers: as vector registers they were spilled, and every
+    // epilogue's re-load waited for the next task's B fragments with it)
+    band = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, band)));
+    tau_fix = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tau_fix)));
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
     const int lr = lane & 15, lq = lane >> 4;
@@ -1699,26 +1704,24 @@ __device__ __forceinline__ void chain_product16(const _Float16* __restrict__ ban
             }
 #endif
         }
+        // candidates: one compare per entry, and a SCALAR branch over the (rare) entry some lane keeps -- a per-lane bit
+        // mask and a select chain per kept entry cost five times the vector instructions
         if (lmax >= thr) {
-            uint32_t mk = 0u;
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) mk |= (acc[mi][rg] >= thr) ? (1u << (4 * mi + rg)) : 0u;
-            while (mk) {
-                const int e = __builtin_ctz(mk);
-                mk &= mk - 1;
-                float v = acc[0][0];
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) v = (e == 4 * mi + rg) ? acc[mi][rg] : v;
-                const int at = atomicAdd(&cl->raw_cnt, 1);
-                if (at < RAW_CAP) {
-                    cl->raw_idx[at] = (prow + 16 * (e >> 2) + (e & 3)) * K + atom;
-                    cl->raw_val[at] = v;
+                for (int rg = 0; rg < 4; ++rg) {
+                    const bool hit = acc[mi][rg] >= thr;
+                    if (__builtin_amdgcn_ballot_w64(hit)) {
+                        if (hit) {
+                            const int at = atomicAdd(&cl->raw_cnt, 1);
+                            if (at < RAW_CAP) {
+                                cl->raw_idx[at] = (prow + 16 * mi + rg) * K + atom;
+                                cl->raw_val[at] = acc[mi][rg];
+                            }
+                        }
+                    }
                 }
-            }
         }
     };
     nt = min(nt, 5);
@@ -1750,13 +1753,12 @@ __device__ __forceinline__ void chain_product16(const _Float16* __restrict__ ban
             for (int mi = 2; mi < 8; ++mi)
                 acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[(2 * PH + mi) % 8], Bf[PH], FIRST ? zero : acc[mi], 0, 0, 0);
             // The fragment BD slabs ahead.  Past the task's end the SAME number of loads goes out (the vmcnt counts are
-            // static), every lane reading ONE 16-byte piece: one cache line for the wave instead of eight.
+            // static): the task's last fragment again, which this wave has just brought into the vector L1.
             {
                 // (uniform base in scalar registers + the lane's fixed 32-bit offset: no vector ALU work for the address
                 // and no address temporaries -- the allocator had put those into ring registers with loads in flight)
-                const bool more = s + BD <= sl;
-                const char* sb = bbase + (more ? tile_off + (unsigned)(s + BD) * (SLABF * 2u) : 0u);
-                Bf[PH] = *reinterpret_cast<const f16x8*>(sb + (more ? lane16 : 0u));
+                const char* sb = bbase + (tile_off + (unsigned)min(s + BD, sl) * (SLABF * 2u));
+                Bf[PH] = *reinterpret_cast<const f16x8*>(sb + lane16);
             }
             ++s;
             __builtin_amdgcn_sched_barrier(0);
@@ -1789,6 +1791,202 @@ __device__ __forceinline__ void chain_product16(const _Float16* __restrict__ ban
         atomicAdd(&g_prof[31][blockIdx.x % PROF_BUCKETS], pt_steps);
     }
 #endif
+}
+
+// build_r16 for the chain kernel, from the LDS copy of the residual: thread t <= R16_CS / 4 converts elements
+// 4t .. 4t + 6 once and writes, for each shift c = 4a + b, the four halves h[4t + b .. 4t + b + 3] as ONE 8-byte store
+// to copy c at index 4 (t - a)  (copy_c[i] = h[i + c]): 8 stores per thread where the element-wise version has 32.
+// (r64 is followed by the r16 copies and the node's structs in LDS, so the reads past the residual's end stay inside
+// the workgroup's allocation; what they return is replaced by zero.)
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void build_r16_quads(const double* r64, int N, float inv, _Float16* r16) {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    if (t <= R16_CS / 4) {
+        _Float16 h[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double v = r64[4 * t + u];
+            h[u] = (4 * t + u < N) ? (_Float16)((float)v * inv) : (_Float16)0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < R16_COPIES; ++c) {
+            const int a = c >> 2, b = c & 3, m = t - a;
+            if (m >= 0 && m < R16_CS / 4) {
+                f16x4 q = {h[b], h[b + 1], h[b + 2], h[b + 3]};
+                *reinterpret_cast<f16x4*>(r16 + c * R16_CS + 4 * m) = q;
+            }
+        }
+    }
+}
+
+// The usual end of a chain level -- at most 8 entries in the fp16 band, at most 4 ancestors -- in five barriers
+// instead of nine (rescore_and_choose + child_solve_and_write remain for everything else, and give the same
+// selections; the solve below multiplies by stored reciprocals where theirs divides, so the last bits of coefficients
+// and MSE may differ between the two, which is why the choice between them depends on deterministic quantities only):
+//   (A) every wave scans the raw list against the final band by itself (same list, same order in all four), takes
+//       candidates 2w, 2w + 1 and re-scores them in float64; barrier; every THREAD takes the choice from the <= 8 scores;
+//   (B) the new Gram column (one dot per wave) while every thread's operands of the residual update -- its elements of
+//       the residual and of the <= 5 placed atoms -- are already on their way from L2; barrier;
+//   (C) thread 0 extends the factor and solves, operands loaded up front, registers only; barrier;
+//   (D) the child's residual from the prefetched operands, its sum of squares; barrier.
+// Returns false when the float64 scores are all NaN (the caller takes the general path; the choice is in sl->...).
+__device__ __forceinline__ bool chain_tail_fast(const LevelArgs& a, NodeLds* sl, ChainLds* cl, double* r64, size_t cid,
+                                                int d, int ncand, int c0, int c1, int wave_s) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int K = a.K, L = a.L, N = a.N;
+    // ---- (A)
+    if (2 * wave_s < ncand) {
+        const bool two = 2 * wave_s + 1 < ncand;
+        const int i0 = c0, i1 = two ? c1 : c0;
+        const int p0 = i0 / K, k0 = i0 - p0 * K, p1 = i1 / K, k1 = i1 - p1 * K;
+        double v0, v1;
+        dot_pair(a.bank64 + (size_t)k0 * L, r64 + p0, a.bank64 + (size_t)k1 * L, r64 + p1, L, lane, v0, v1);
+        v0 = wave_sum(v0);
+        v1 = wave_sum(v1);
+        if (lane == 63) {
+            sl->cand_val[2 * wave_s] = v0;
+            sl->cand_idx[2 * wave_s] = i0;
+            if (two) { sl->cand_val[2 * wave_s + 1] = v1; sl->cand_idx[2 * wave_s + 1] = i1; }
+        }
+    }
+    PROF_MARK(2);
+    __syncthreads();
+    double bestv = sl->cand_val[0];
+    int chosen = sl->cand_idx[0];
+    for (int c = 1; c < ncand; ++c) {
+        const double v = sl->cand_val[c];
+        const int i = sl->cand_idx[c];
+        if (v > bestv || (v == bestv && i < chosen)) { bestv = v; chosen = i; }
+    }
+    const bool ok = bestv == bestv && (unsigned)chosen < (unsigned)(a.P * K);
+    if ((unsigned)chosen >= (unsigned)(a.P * K)) chosen = 0;
+    const int p_sel = chosen / K, k_sel = chosen - p_sel * K;
+    if (tid == 0) {
+        if (a.stats) atomicAdd(&a.stats[2], ncand);
+        sl->chosen = chosen;
+        sl->sup_pos[d] = p_sel;
+        sl->sup_atom[d] = k_sel;
+        sl->beta = bestv;
+        sl->beta_ok = ok ? 1 : 0;
+    }
+    if (!ok) { __syncthreads(); return false; }
+    PROF_MARK(5);
+    // ---- (B)
+    const double* an = a.bank64 + (size_t)k_sel * L;
+    const double gdd = a.anorm2[k_sel];
+    double av[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int ii = min(i, d);
+        const int pi = ii == d ? p_sel : sl->sup_pos[ii];
+        const double* ai = ii == d ? an : a.bank64 + (size_t)sl->sup_atom[ii] * L;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int o = tid + WG * u - pi;
+            av[i][u] = ((unsigned)o < (unsigned)L && i <= d) ? ai[o] : 0.0;
+        }
+    }
+    for (int q = wave_s; q < d; q += WG / 64) {
+        const double* aq = a.bank64 + (size_t)sl->sup_atom[q] * L;
+        const int dp = p_sel - sl->sup_pos[q];
+        double w = dot_range<64>(an, aq + dp, max(0, -dp), min(L, L - dp), lane);
+        w = wave_sum(w);
+        if (lane == 63) sl->g[q] = w;
+    }
+    PROF_MARK(4);
+    __syncthreads();
+    PROF_MARK(6);
+    // ---- (C)
+    if (tid == 0) {
+        double l[TRI(4)], li[4], g[4], cp[4];
+#pragma unroll
+        for (int i = 0; i < TRI(4); ++i) l[i] = i < TRI(d) ? sl->Lf[i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            li[i] = i < d ? cl->Linv[i] : 0.0;
+            g[i] = i < d ? sl->g[i] : 0.0;
+            cp[i] = i < d ? sl->coefpar[i] : 0.0;
+        }
+        double y[4], x[5], yy = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double w = g[i];
+#pragma unroll
+            for (int m = 0; m < i; ++m) w = fma(-l[TRI(i) + m], y[m], w);   // (explicit: the same roundings as the general solve)
+            w = (li[i] != 0.0) ? w * li[i] : 0.0;
+            y[i] = w;
+            yy = fma(w, w, yy);
+        }
+        const double sdd = gdd - yy;
+        const bool bad = !(sdd > 1e-13 * gdd);
+        double ydd = 0.0, xd = 0.0, lid = 0.0;
+        if (bad) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = 0.0;
+        } else {
+            ydd = sqrt(sdd);
+            xd = bestv / sdd;
+            lid = 1.0 / ydd;
+        }
+#pragma unroll
+        for (int r = 3; r >= 0; --r) {
+            double w = -y[r] * xd;
+#pragma unroll
+            for (int m = r + 1; m < 4; ++m) w = fma(-l[TRI(m) + r], x[m], w);
+            x[r] = (li[r] != 0.0) ? w * li[r] : 0.0;
+        }
+        // (rows >= d of l, li, y are zero, so x[r] = 0 there and the sums above skip them)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < d) {
+                sl->x[i] = x[i];
+                sl->Lf[TRI(d) + i] = y[i];
+                sl->coefpar[i] = x[i] + cp[i];
+            }
+        sl->x[d] = xd;
+        sl->Lf[TRI(d) + d] = ydd;
+        sl->coefpar[d] = xd;
+        cl->Linv[d] = lid;
+        if (bad && a.stats) atomicAdd(&a.stats[1], 1);
+    }
+    __syncthreads();
+    PROF_MARK(7);
+    // ---- (D)
+    double cs = 0.0, v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int n = tid + WG * u;
+        v[u] = n < N ? r64[n] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const double xi = i <= d ? sl->x[min(i, d)] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = fma(-xi, av[i][u], v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int n = tid + WG * u;
+        if (n < N) {
+            r64[n] = v[u];
+            cs = fma(v[u], v[u], cs);
+        }
+    }
+    cs = wave_sum(cs);
+    if (lane == 63) sl->wsum[wave_s] = cs;
+    if (tid < a.Kmax && a.node_coef) a.node_coef[cid * a.Kmax + tid] = tid <= d ? sl->coefpar[tid] : 0.0;
+    PROF_MARK(10);
+    __syncthreads();
+    if (tid == 0) {
+        a.node_pos[cid] = p_sel;
+        a.node_atom[cid] = k_sel;
+        a.node_mse[cid] = (sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3]) / (double)N;
+    }
+    PROF_MARK(8);
+    return true;
 }
 
 __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
@@ -1837,6 +2035,10 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
     const float am2 = *a.amax2, am = sqrtf(am2);
     const float band = 2.f * ((9.765625e-04f + DELTA_REL + 1e-6f) * am + 2.9802322e-08f * sqrtf((float)L) * (1.f + am));
     if (tid == 0) a.flags[s * Fd + j] = 0;
+    if (tid < (a.from_root ? 1 : d0)) {                               // reciprocal diagonal of the factor brought along
+        const double dg = sl->Lf[TRI(tid) + tid];
+        cl->Linv[tid] = dg != 0.0 ? 1.0 / dg : 0.0;
+    }
     __syncthreads();                                                  // the task table
     // the wave's task descriptors, packed into scalar registers
     const unsigned desc01 = (unsigned)__builtin_amdgcn_readfirstlane((int)(cl->desc[wave][0] | (cl->desc[wave][1] << 16)));
@@ -1864,20 +2066,7 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
     for (int d = d0; d < a.Kmax; ++d) {
         // NaN / Inf / extreme scales, an all-zero atom: fp32
         if (zero_atoms || !(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 1e-30 && rnorm2 < 1e30)) { give_up(d); return; }
-        {
-            // the window elements build_r16 wants in registers, from the LDS copy on every level (carried from the
-            // prologue in registers they lived in scratch across the level loop)
-            const float inv = (float)(1.0 / sqrt(rnorm2));
-            int tq = threadIdx.x;
-            asm volatile("" : "+v"(tq));
-            double win[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = tq + WG * u;
-                win[u] = i < N ? r64[i] : 0.0;
-            }
-            build_r16(r64, N, inv, win, r16);
-        }
+        build_r16_quads(r64, N, (float)(1.0 / sqrt(rnorm2)), r16);
         if (tid == 0) { sl->cand_cnt = 0; cl->raw_cnt = 0; cl->gkey = fkey(-INFINITY); }
         WAIT_VM(0);                                                   // (the product counts its own loads)
         __syncthreads();
@@ -1916,6 +2105,50 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
             __syncthreads();
             nraw = cl->raw_cnt;
             if (nraw > RAW_CAP) { give_up(d); return; }               // a flat residual: fp32
+        }
+        // the usual case -- a handful of entries in the final band, a shallow support -- goes through chain_tail_fast.
+        // Every wave scans the raw list by itself: the same list in the same order, so the four agree on the number of
+        // candidates and on who re-scores which without a barrier.  (The choice of path rests on that NUMBER, which does
+        // not depend on the order the tasks finished in; the list's order does.)
+        const size_t cid = s * a.NN + a.ts.off[d + 1] + j;
+        bool fast = false;
+        if (a.mode == 0 && d <= 4) {
+            const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+            int ncand = 0, c0 = 0, c1 = 0;
+            for (int base = 0; base < nraw; base += 64) {
+                const int i = base + lane;
+                const bool pass = i < nraw && cl->raw_val[i] >= tau;
+                const int idx = i < nraw ? cl->raw_idx[i] : 0;
+                unsigned long long m = __ballot(pass);
+                while (m) {
+                    const int pos = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int id = __builtin_amdgcn_readlane(idx, pos);
+                    if (ncand == 2 * wave_s) c0 = id;
+                    if (ncand == 2 * wave_s + 1) c1 = id;
+                    ++ncand;
+                }
+            }
+            if (ncand >= 1 && ncand <= 8) {
+                PROF_MARK(3);
+#ifdef CSC_CAND_ORDER
+                const size_t node = ((size_t)s * Fd + j) * a.Kmax + d;
+#endif
+                fast = chain_tail_fast(a, sl, cl, r64, cid, d, ncand, c0, c1, wave_s);
+#ifdef CSC_CAND_ORDER
+                if (node < CAND_DUMP_NODES) {                         // (the list is in sl->cand_idx behind the tail's barriers)
+                    if (tid == 0) { g_cand_dump[node][0] = force_final ? nraw : nraw_first; g_cand_dump[node][1] = ncand; }
+                    if (tid < ncand) g_cand_dump[node][2 + tid] = sl->cand_idx[tid];
+                }
+#endif
+                if (!fast) {                                          // all-NaN scores: the general solve on the choice made
+                    child_solve_and_write(a, sl, r64, s, j, cid, d, nullptr, true);
+                    __syncthreads();
+                    if (tid == 0) { const double dg = sl->Lf[TRI(d) + d]; cl->Linv[d] = dg != 0.0 ? 1.0 / dg : 0.0; }
+                }
+                rnorm2 = sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3];
+                continue;
+            }
         }
         {
             int tq = threadIdx.x;
@@ -1970,9 +2203,9 @@ __device__ __forceinline__ void lean_chain(const LevelArgs& a) {
             __syncthreads();
         }
         PROF_MARK(5);
-        const size_t cid = s * a.NN + a.ts.off[d + 1] + j;
         child_solve_and_write(a, sl, r64, s, j, cid, d, nullptr, true);
         __syncthreads();
+        if (tid == 0) { const double dg = sl->Lf[TRI(d) + d]; cl->Linv[d] = dg != 0.0 ? 1.0 / dg : 0.0; }
         rnorm2 = sl->wsum[0] + sl->wsum[1] + sl->wsum[2] + sl->wsum[3];   // the child's ||residual||^2
     }
     PROF_MARK(9);

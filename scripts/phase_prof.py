@@ -31,8 +31,11 @@ for title, base, nodes in rows:
     w = v[base:base + 12]
     tot = w.sum()
     print(title)
+    if base == 16:
+        names = ["prologue", "build r16 + product", "re-score: dots + wave sums (before the barrier)", "wait for the product's last wave + scan of the raw list", "gram dots + prefetch (before the barrier)", "re-score: barrier + choice",
+                 "gram: barrier", "solve", "residual: barrier + node tables", "tail", "residual update (before the barrier)", "-"]
     for n, x in zip(names, w):
-        print(f"  {n:18s} {x / nodes:10.0f} clk/node  {100 * x / max(tot, 1):5.1f} %")
+        print(f"  {n:60s} {x / nodes:10.0f} clk/node  {100 * x / max(tot, 1):5.1f} %")
     print(f"  total {tot / nodes:.0f} clk/node")
 
 if lean:
