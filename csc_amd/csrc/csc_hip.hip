@@ -1877,14 +1877,16 @@ __device__ __forceinline__ bool chain_tail_fast(const LevelArgs& a, NodeLds* sl,
     // ---- (B)
     const double* an = a.bank64 + (size_t)k_sel * L;
     const double gdd = a.anorm2[k_sel];
-    double av[5][4];
+    // (elements tid, tid + 256, tid + 512 of the window; a fourth, N > 768, is not prefetched: the registers it would
+    // hold across the solve were spilled, 300 MB of scratch writes per launch)
+    double av[5][3];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int ii = min(i, d);
         const int pi = ii == d ? p_sel : sl->sup_pos[ii];
         const double* ai = ii == d ? an : a.bank64 + (size_t)sl->sup_atom[ii] * L;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 3; ++u) {
             const int o = tid + WG * u - pi;
             av[i][u] = ((unsigned)o < (unsigned)L && i <= d) ? ai[o] : 0.0;
         }
@@ -1955,9 +1957,9 @@ __device__ __forceinline__ bool chain_tail_fast(const LevelArgs& a, NodeLds* sl,
     __syncthreads();
     PROF_MARK(7);
     // ---- (D)
-    double cs = 0.0, v[4];
+    double cs = 0.0, v[3];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 3; ++u) {
         const int n = tid + WG * u;
         v[u] = n < N ? r64[n] : 0.0;
     }
@@ -1965,14 +1967,27 @@ __device__ __forceinline__ bool chain_tail_fast(const LevelArgs& a, NodeLds* sl,
     for (int i = 0; i < 5; ++i) {
         const double xi = i <= d ? sl->x[min(i, d)] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = fma(-xi, av[i][u], v[u]);
+        for (int u = 0; u < 3; ++u) v[u] = fma(-xi, av[i][u], v[u]);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 3; ++u) {
         const int n = tid + WG * u;
         if (n < N) {
             r64[n] = v[u];
             cs = fma(v[u], v[u], cs);
+        }
+    }
+    if (N > 3 * WG) {                                                 // (uniform) the window's fourth quarter, loaded here
+        const int n = tid + 3 * WG;
+        if (n < N) {
+            double w = r64[n];
+            for (int i = 0; i <= d; ++i) {
+                const int o = n - (i == d ? p_sel : sl->sup_pos[i]);
+                const double* ai = i == d ? an : a.bank64 + (size_t)sl->sup_atom[i] * L;
+                w = fma(-sl->x[i], ((unsigned)o < (unsigned)L) ? ai[o] : 0.0, w);
+            }
+            r64[n] = w;
+            cs = fma(w, w, cs);
         }
     }
     cs = wave_sum(cs);
