@@ -685,6 +685,129 @@ __global__ __launch_bounds__(WG, 2) void correlate_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// similarity table on the matrix cores (csc_similarity_table_packed): the same bits as sim_table_kernel
+// ------------------------------------------------------------------------------------------------
+// sim_table_kernel takes every cross-correlation in float64 on the vector ALUs: 25 TMAC for the 9570-atom dictionary of
+// config 3, 6.2 s.  Here one workgroup per selected atom treats that atom, zero-padded by P - 1 samples on both sides,
+// as a signal and correlates it with the packed bank exactly like correlate_kernel does (fp32 matrix cores, the
+// (256 shifts x 144 columns) tile in registers); an entry is decided by the fp32 value wherever that value is further
+// from the threshold than the product's rounding bound, and recomputed the way sim_table_kernel computes it -- the same
+// float64 sum in the same order -- where it is not (a few hundred of the 5 M entries of an atom).  The bits of a bank
+// tile are collected in LDS and leave as whole rows.
+#define SIMQ 2048                      // undecided entries of one bank tile (queue in LDS; more: the whole tile in float64)
+__global__ __launch_bounds__(WG, 2) void sim_table_mfma_kernel(const float* __restrict__ bank32t, const int32_t* __restrict__ meta,
+                                                               const float* __restrict__ amax2, const double* __restrict__ bank64,
+                                                               int K, int L, int Lp, int P, int W, double thr,
+                                                               uint32_t* __restrict__ bits) {
+    extern __shared__ float lds[];
+    __shared__ uint32_t masks[MAX_SLABS];
+    __shared__ double wpart[WG / 64];
+    __shared__ int qn;
+    const int nshift = 2 * P - 1;
+    const int nrb = (nshift + CSC_TILE_ROWS - 1) / CSC_TILE_ROWS;
+    const int R32 = CSC_TILE_ROWS * nrb + Lp + 4;
+    float* slab = lds;                                                 // [2][SLABF]
+    float* r32 = lds + 2 * SLABF;                                      // [R32]: the selected atom at offset P - 1, zeros around
+    uint32_t* tbits = reinterpret_cast<uint32_t*>(r32 + ((R32 + 3) & ~3));   // [144][W]: the bits of the current bank tile
+    uint32_t* queue = tbits + CSC_TILE_COLS * W;                       // [SIMQ]: column << 16 | shift index
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int ksel = blockIdx.x;
+    const double* asel = bank64 + (size_t)ksel * L;
+    double ss = 0.0;
+    for (int i = tid; i < L; i += WG) {                               // (sim_table_kernel's norm, the same sum)
+        const double v = asel[i];
+        ss += v * v;
+    }
+    ss = wave_sum(ss);
+    if (lane == 63) wpart[wave] = ss;
+    for (int i = tid; i < R32; i += WG) {
+        const int o = i - (P - 1);
+        r32[i] = ((unsigned)o < (unsigned)L) ? (float)asel[o] : 0.f;
+    }
+    __syncthreads();
+    const double nrm = sqrt(wpart[0] + wpart[1] + wpart[2] + wpart[3]);
+    // decided by the fp32 value: |fp32 product - float64 sum| <= (L + 8) 2^-23 ||a_sel|| max_k ||a_k|| (both operands
+    // rounded to fp32, L fp32 accumulations), doubled
+    const float T = (float)(thr * nrm);
+    const float dlt = 2.f * (float)(L + 8) * 1.1920929e-07f * (float)nrm * sqrtf(*amax2) + 2.3841858e-07f * fabsf(T);
+    const int ntile = (K + CSC_TILE_COLS - 1) / CSC_TILE_COLS;
+    const int nslab = (L + SLAB - 1) / SLAB;
+    // sim_table_kernel's decision for (bank column c of the tile, shift index dpi), the same float64 sum in the same order
+    auto exact = [&](int tl, int c, int dpi) {
+        const int k = meta[tl * META_INTS + c];
+        if (k < 0 || dpi >= nshift) return;
+        const int dp = dpi - (P - 1);
+        const int j0 = max(0, -dp), j1 = min(L, L - dp);
+        const double* ak = bank64 + (size_t)k * L;
+        double e = 0.0;
+        for (int j = j0; j < j1; ++j) e = fma(ak[j], asel[j + dp], e);
+        if ((e / nrm) > thr) atomicOr(&tbits[c * W + (dpi >> 5)], 1u << (dpi & 31));
+    };
+    for (int tl = 0; tl < ntile; ++tl) {
+        __syncthreads();
+        if (tid < nslab) masks[tid] = (uint32_t)meta[tl * META_INTS + CSC_TILE_COLS + tid];
+        for (int i = tid; i < CSC_TILE_COLS * W; i += WG) tbits[i] = 0u;
+        if (tid == 0) qn = 0;
+        int permv[NT];
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) permv[ni] = meta[tl * META_INTS + 16 * ni + lr];
+        __syncthreads();
+        for (int rb = 0; rb < nrb; ++rb) {
+            f32x4 acc[MT][NT];
+            corr_tile_gemm(bank32t + (size_t)tl * nslab * SLABF, masks, nslab,
+                           r32 + rb * CSC_TILE_ROWS + 64 * wave + lr + lq, slab, acc);
+            // this lane's entries of (row tile mi, column tile ni): shifts dpi0 + rg, four bits of the column's row
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                if (permv[ni] < 0) continue;
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    const int dpi0 = rb * CSC_TILE_ROWS + 64 * wave + 16 * mi + 4 * lq;
+                    unsigned four = 0u, open4 = 0u;
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const float v = acc[mi][ni][rg];
+                        four |= (v > T + dlt) ? 1u << rg : 0u;
+                        open4 |= !(v > T + dlt || v < T - dlt) ? 1u << rg : 0u;       // too close to call (or not a number)
+                    }
+                    if (dpi0 >= nshift) continue;
+                    if (dpi0 + 3 >= nshift) {                          // (the table's last shifts: nothing beyond them)
+                        four &= (1u << (nshift - dpi0)) - 1u;
+                        open4 &= (1u << (nshift - dpi0)) - 1u;
+                    }
+                    if (four) atomicOr(&tbits[(16 * ni + lr) * W + (dpi0 >> 5)], four << (dpi0 & 31));
+                    while (open4) {
+                        const int rg = __builtin_ctz(open4);
+                        open4 &= open4 - 1;
+                        const int slot = atomicAdd(&qn, 1);
+                        if (slot < SIMQ) queue[slot] = ((unsigned)(16 * ni + lr) << 16) | (unsigned)(dpi0 + rg);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int nq = qn;
+        if (nq <= SIMQ) {
+            for (int i = tid; i < nq; i += WG) exact(tl, (int)(queue[i] >> 16), (int)(queue[i] & 0xffffu));
+        } else {
+            // (degenerate: thousands of entries at the threshold) the whole tile in float64
+            __syncthreads();
+            for (int i = tid; i < CSC_TILE_COLS * W; i += WG) tbits[i] = 0u;
+            __syncthreads();
+            for (int i = tid; i < CSC_TILE_COLS * nshift; i += WG) exact(tl, i / nshift, i % nshift);
+        }
+        __syncthreads();
+        // the tile's rows out: W words per (selected atom, column's atom), contiguous
+        for (int i = tid; i < CSC_TILE_COLS * W; i += WG) {
+            const int c = i / W, w = i - c * W;
+            const int k = meta[tl * META_INTS + c];
+            if (k >= 0) bits[((size_t)ksel * K + k) * W + w] = tbits[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // float64 correlations for the public API (computeCorrelations / the rmatvec of getMaskedConvOperator)
 // ------------------------------------------------------------------------------------------------
 // The matrix-core kernel above returns fp32-accurate values; a caller that runs its own solver on the operator (lsqr's
@@ -3865,6 +3988,26 @@ int csc_similarity_table(const double* d_bank64, int K, int L, int N, double thr
     hipLaunchKernelGGL(sim_table_kernel, dim3(K, K), dim3(WG), (size_t)2 * L * sizeof(double),
                        (hipStream_t)stream, d_bank64, K, L, P, W, threshold, d_sim_bits);
     return launch_status("sim_table_kernel");
+}
+
+int csc_similarity_table_packed(const float* d_bank32t, const double* d_bank64, int K, int L, int N, double threshold,
+                                uint32_t* d_sim_bits, void* stream) {
+    const int P = N - L + 1;
+    if (!d_bank32t || !d_bank64 || !d_sim_bits || K <= 0 || L <= 0) FAIL(-1, "csc_similarity_table_packed: bad arguments");
+    if (P <= 0) FAIL(-6, "signal length %d shorter than atom length %d", N, L);
+    const int W = csc_sim_words(N, L);
+    const int Lp = n_slabs(L) * SLAB;
+    const int nrb = (2 * P - 1 + CSC_TILE_ROWS - 1) / CSC_TILE_ROWS;
+    const int R32 = CSC_TILE_ROWS * nrb + Lp + 4;
+    const size_t lds = (size_t)2 * SLABF * 4 + (size_t)ceil4(R32) * 4 + (size_t)CSC_TILE_COLS * W * 4 + SIMQ * 4;
+    // long atoms or very long signals (the shift index travels in 16 bits): the float64 kernel (same bits)
+    if (n_slabs(L) > MAX_SLABS || lds > 72 * 1024 || 2 * P - 1 > 65535)
+        return csc_similarity_table(d_bank64, K, L, N, threshold, d_sim_bits, stream);
+    clear_stale_error();
+    hipFuncSetAttribute((const void*)sim_table_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(sim_table_mfma_kernel, dim3(K), dim3(WG), lds, (hipStream_t)stream, d_bank32t, bank_meta(d_bank32t, K, L),
+                       bank_amax2(d_bank32t, K, L), d_bank64, K, L, Lp, P, W, threshold, d_sim_bits);
+    return launch_status("sim_table_mfma_kernel");
 }
 
 int csc_correlate(const float* d_bank32t, int K, int L, const double* d_signals, int B, int N,

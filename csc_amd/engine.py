@@ -156,9 +156,11 @@ class DeviceBank:
                 raise ValueError(f"signal length {N} shorter than atom length {self.L}")
             with torch.cuda.device(self.device):
                 bits = torch.empty(self.K * self.K * W, dtype=torch.int32, device=self.device)
-                _lib.check(self.lib.csc_similarity_table(_ptr(self.bank64), self.K, self.L, N,
-                                                         float(threshold), _ptr(bits),
-                                                         _stream(self.device)), "csc_similarity_table")
+                # (the packed-bank entry: fp32 matrix cores + float64 where the fp32 value is too close to the
+                # threshold -- the same bits as csc_similarity_table, an order of magnitude sooner on large dictionaries)
+                _lib.check(self.lib.csc_similarity_table_packed(_ptr(self.bank32t), _ptr(self.bank64), self.K, self.L, N,
+                                                                float(threshold), _ptr(bits),
+                                                                _stream(self.device)), "csc_similarity_table_packed")
             self._sim[key] = bits
         return self._sim[key]
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CSC_ABI_VERSION 5
+#define CSC_ABI_VERSION 6
 #define CSC_TILE_COLS 144      /* atoms per column tile of the correlation kernel (9 x 16)   */
 #define CSC_TILE_ROWS 256      /* positions per row tile (4 waves x 4 x 16)                   */
 #define CSC_MAX_SPARSITY 16    /* largest tree depth / support size                           */
@@ -59,6 +59,14 @@ int csc_bank_pack(const double* d_bank64, int K, int L, float* d_bank32t, void* 
  * every placement is 'valid').  d_sim_bits [K][K][csc_sim_words(N, L)] uint32. */
 int csc_similarity_table(const double* d_bank64, int K, int L, int N, double threshold,
                          uint32_t* d_sim_bits, void* stream);
+
+/* The same table, bit for bit, from the PACKED bank (csc_bank_pack's image) on the fp32 matrix cores: an entry is
+ * decided by the fp32 cross-correlation wherever that is further from the threshold than its rounding bound and
+ * recomputed in float64, as csc_similarity_table computes it, where it is not.  6.2 s -> well under a second for the
+ * 9570-atom dictionary of BASELINE config 3 (same reference lines: src/csc/mmp.py:92-93, 196-201).  Falls back to
+ * csc_similarity_table for atoms longer than the packed bank's slabs cover. */
+int csc_similarity_table_packed(const float* d_bank32t, const double* d_bank64, int K, int L, int N, double threshold,
+                                uint32_t* d_sim_bits, void* stream);
 
 /* Batched valid cross-correlation on fp32 MFMA.  Replaces CSCDictionary.computeCorrelations
  * (src/csc/dictionary.py:395-407) for B signals at once.

@@ -252,3 +252,36 @@ def test_tiled_fp16_front_equals_fp32_on_random_dictionaries():
         assert fuzz_tiled.run(14, 7, verbose=False) == 0
     finally:
         os.chdir(cwd)
+
+
+def test_similarity_table_packed_equals_float64_kernel():
+    """csc_similarity_table_packed (fp32 matrix cores, float64 where the fp32 value is too close to the threshold to
+    call) against csc_similarity_table (float64 throughout): the same bits, on the canonical dictionary, on a
+    330-atom dictionary with P = 260 (several bank tiles, three blocks of shifts) and on thresholds that sit in the
+    middle of the cross-correlations' range (thousands of undecided entries per tile: the queue and its overflow path)."""
+    import ctypes as C
+    import torch
+    import csc_amd
+    from csc_amd import _lib
+
+    def ptr(t):
+        return C.c_void_p(t.data_ptr())
+
+    cases = [(csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.005), np.arange(0.010, 0.036, 0.002), [1]), 738, (0.8, 0.3, 1e-9, -0.5)),
+             (csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.0025), np.arange(0.010, 0.036, 0.0018), [1]), None, (0.8, 0.65))]
+    for d, N, thrs in cases:
+        bank = d.device_bank()
+        lib = bank.lib
+        if N is None:
+            N = bank.L + 259
+        W = lib.csc_sim_words(N, bank.L)
+        for thr in thrs:
+            a = torch.full((bank.K * bank.K * W,), 0x5a5a5a5a, dtype=torch.int32, device=bank.device)
+            b = torch.full_like(a, 0x33333333)
+            stream = C.c_void_p(torch.cuda.current_stream(bank.device).cuda_stream)
+            _lib.check(lib.csc_similarity_table(ptr(bank.bank64), bank.K, bank.L, N, thr, ptr(a), stream), "csc_similarity_table")
+            _lib.check(lib.csc_similarity_table_packed(ptr(bank.bank32t), ptr(bank.bank64), bank.K, bank.L, N, thr, ptr(b), stream),
+                       "csc_similarity_table_packed")
+            torch.cuda.synchronize(bank.device)
+            assert torch.equal(a, b), (bank.K, N, thr, int((a != b).sum()))
+            assert int(a.count_nonzero()) > 0 or thr > 0.9
