@@ -63,7 +63,7 @@ FP16_MFMA_PEAK_TFLOPS = 2500.0     # same guide, "Peak BF16/FP16 MFMA": ~2.5 PF 
 HBM_PEAK_GBS = 8000.0              # same guide, "HBM3E peak BW": 8.0 TB/s spec
 CPU_SAMPLE = [i * PER_CELL + o for i in range(16) for o in (7, 107)]    # two signals of every (snr, sparsity) cell: ~25 CPU-s
 CONFIG5_PER_RANK = 125000
-TRAFFIC_PROFILE = os.path.join("profiles", "r02_hbm_traffic.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r03_hbm_traffic.json")
 
 
 def canonical_dictionary():
