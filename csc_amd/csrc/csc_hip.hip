@@ -116,6 +116,9 @@ struct LevelArgs {
     int S;                // signals
     const double* signals;    // [S][N]            } the chain kernels walk several levels: level e reads
     double* ws[2];            // [S][F][NS] each   } signals (e == 0) or ws[e & 1] and writes ws[(e + 1) & 1]
+    const float* lr_u32;      // low-rank screen (CSC_FLAG_LOWRANK): the basis as one fp32 bank tile | nullptr
+    const _Float16* lr_v16;   //   basis coefficients of the bank's columns, fp16 B fragments [16-column block][k-step][lane][8]
+    const float* lr_slack;    //   per bank column: what the low-rank product can miss of a correlation, in units of ||r||
     int sibling;          // screen16_kernel / mmp_level_tiled16_kernel: the one child (sibling) of each node this launch selects
     int picks_only;       // level 0 ahead of the chain kernel: write the children's (pos, atom) and <atom, signal> only
     int from_root;        // chain kernel: build the level-1 node from the signal and the root level's pick
@@ -3010,7 +3013,8 @@ __device__ __forceinline__ void gemm16x1_group(const _Float16* __restrict__ hi, 
 template <bool REM>
 __device__ __forceinline__ void screen_blocks16(const LevelArgs& a, const _Float16* __restrict__ hi_all, unsigned* key,
                                                 const unsigned short* brange, int ntile, int nslab, int nrb,
-                                                const _Float16* rh, int R16T_CS, _Float16* ring, int nsup, const int* spick) {
+                                                const _Float16* rh, int R16T_CS, _Float16* ring, int nsup, const int* spick,
+                                                const unsigned char* need = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
@@ -3024,10 +3028,15 @@ __device__ __forceinline__ void screen_blocks16(const LevelArgs& a, const _Float
         if (p.blk >= NT) { p.blk -= NT; if (++p.tile == ntile) { p.tile = 0; ++p.rb; } }
     };
     // slab range of a block: outside it the block is zero padding (brange[block + 9 tile] = s0 | s1 << 8, built by the caller)
+    // `need` (behind the low-rank screen): only the units marked there are multiplied; the others keep the bound they have
+    auto skipped = [&](const Pos& p) -> bool {
+        return need && !__builtin_amdgcn_readfirstlane((int)need[p.blk / NG + NG * (p.tile + ntile * p.rb)]);
+    };
     auto block_range = [&](const Pos& p, int& s0, int& s1) {
         const int pk = __builtin_amdgcn_readfirstlane((int)brange[p.blk + NT * p.tile]);
         s0 = pk & 0xff;
         s1 = pk >> 8;
+        if (skipped(p)) s0 = s1 = 0;
     };
     // the wave's stream of B blocks: copy cursor (starts one stride before the wave's first block)
     Pos cp = {wave - 4, 0, 0};
@@ -3078,6 +3087,7 @@ __device__ __forceinline__ void screen_blocks16(const LevelArgs& a, const _Float
     for (; p.rb < nrb; advance(p)) {
         int s0, s1;
         block_range(p, s0, s1);
+        if (skipped(p)) continue;
         const int rowbase = p.rb * CSC_TILE_ROWS;
         const int rows = min(P - rowbase, CSC_TILE_ROWS + ((REM && p.rb == nrb - 1) ? 16 : 0));   // valid rows of the block
         const bool colok = p.tile * CSC_TILE_COLS + 16 * p.blk + lr >= npad;
@@ -3305,11 +3315,279 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
     }
     __syncthreads();
     const _Float16* hi_all = reinterpret_cast<const _Float16*>(a.bank16);
-    if (rem) screen_blocks16<true>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring, t, spick);
-    else screen_blocks16<false>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring, t, spick);
+    float* tab = screen_table(a, s, j, d, t);
+    const unsigned char* need = nullptr;
+    if (a.lr_u32) {
+        // behind screen_lr_kernel: its table holds, per unit, an upper bound (less e1) of what the unit can hold and, behind
+        // the units, a lower bound LB of the node's maximum.  A unit whose bound + e1 + band / 2 (the most the three-product
+        // sweep can find there) stays 2 bands below LB - band / 2 (the least its running maximum ends at) is never visited
+        // and keeps its bound; the single-term product tightens the others.
+        unsigned char* nd = reinterpret_cast<unsigned char*>(spick + 2 * CSC_MAX_CONNECTIONS);
+        const float am = sqrtf(am2);
+        const float toacc = 64.f * split_scale(am2);
+        const float e1 = (9.765625e-4f + 6.103515625e-05f + 1e-6f) * am + 2.98023223876953125e-08f * sqrtf((float)L) * (1.f + am);
+        const float band = 2.f * ((EPS3_ACC + 9.5367431640625e-07f) * am + 1.862645149230957e-09f * sqrtf((float)L) * (1.f + am));
+        const float lb = tab[nunits];
+        for (int u = tid; u < nunits; u += WG) {
+            const float ub = tab[u];
+            const bool skip = ub + (e1 + 0.5f * band) * toacc < lb - 2.5f * band * toacc;     // (false on NaN: multiplied)
+            nd[u] = skip ? 0 : 1;
+            if (skip) key[u] = fkey(ub);
+        }
+        need = nd;
+        __syncthreads();
+    }
+    if (rem) screen_blocks16<true>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring, t, spick, need);
+    else screen_blocks16<false>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring, t, spick, need);
+    __syncthreads();
+    for (int u = tid; u < nunits; u += WG) tab[u] = fkey_inv(key[u]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// low-rank screen of large dictionaries (CSC_FLAG_LOWRANK; csc_bank_lowrank installs the section it reads)
+// ------------------------------------------------------------------------------------------------
+// A finely sampled dictionary spans little: the 9570 atoms of BASELINE config 3 lie within 1e-3 (median; 4e-3 at most) of
+// the span of 64 orthonormal vectors U.  With V = U^T a_k (coefficients, rounded to fp16: V16) and res_k = a_k - U V16_k
+//     <r_window, a_k> = (r_window U) V16_k + <r_window, res_k>,     |<r_window, res_k>| <= ||r|| ||res_k||
+// so C~ = T V16 with T = R U -- the Hankel product against 64 columns instead of K, then a GEMM of depth 64: 34 MFMAs per
+// 16-column block where the single-term screen issues ~190 -- bounds every correlation of a column to within
+//     slack_k = ||res_k|| + (2^-11 + sqrt(64) (L + 8) 2^-23 + 64 2^-24 + 2^-20) ||V16_k||        (units of ||r||)
+// (T rounded to fp16; T itself from the fp32 matrix cores: both operands rounded to fp32, L accumulations per entry, 64
+// entries per row; the fp32 accumulation of the second product; fp16 subnormals of T).  Any basis is valid -- the slack is
+// computed from the V16 actually used -- as long as its vectors are orthonormal (||T_p|| <= ||r_window||).
+// screen_lr_kernel leaves per unit  max(C~ + slack) - e1  in the screen table (mmp_level_tiled16_kernel adds e1 back) and,
+// behind the units, a LOWER bound of the node's maximum: max(C~ - slack).  screen16_kernel, launched behind, then takes
+// the single-term product only of the units whose low-rank bound can still reach that maximum (a tenth of them).
+#define LR_R 64                        // rank of the screen
+#define LR_TS (LR_R + 8)               // row stride of T in LDS (halves): 144 B, 16-byte aligned rows
+#define LR_AREA_F ((2 * SLABF > 272 * LR_TS / 2) ? 2 * SLABF : 272 * LR_TS / 2)   // floats: the slab buffers, then T16
+
+__global__ void lr_pack_u_kernel(const double* __restrict__ basis, int L, int nslab, float* __restrict__ u32) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nslab * SLABF) return;
+    const int col16 = (int)(i & 15), row = (int)((i >> 4) & (SLAB - 1));
+    size_t t = i / BLKF;
+    const int ni = (int)(t % NT);
+    const int slab = (int)(t / NT);
+    const int c = 16 * ni + col16 - (CSC_TILE_COLS - LR_R);           // the basis sits in the tile's LAST columns
+    const int l = slab * SLAB + row;
+    u32[i] = (c >= 0 && l < L) ? (float)basis[(size_t)c * L + l] : 0.f;
+}
+// V16[block][ks][lane][j] = fl16(2^sa <U_i, a_k>), i = 32 ks + 8 (lane >> 4) + j, k = atom of column 16 block + (lane & 15)
+__global__ void lr_pack_v_kernel(const double* __restrict__ basis, const double* __restrict__ bank64, int K, int L,
+                                 const int32_t* __restrict__ meta, const float* __restrict__ amax2,
+                                 _Float16* __restrict__ v16, size_t total) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), ks = (int)((e >> 9) % (LR_R / 32));
+    const size_t blk = e / (512 * (LR_R / 32));
+    const int tile = (int)(blk / NT), ni = (int)(blk % NT);
+    const int k = meta[tile * META_INTS + 16 * ni + (lane & 15)];
+    const int i = 32 * ks + 8 * (lane >> 4) + j;
+    double v = 0.0;
+    if (k >= 0) {
+        const double* u = basis + (size_t)i * L;
+        const double* ak = bank64 + (size_t)k * L;
+        for (int l = 0; l < L; ++l) v = fma(u[l], ak[l], v);
+    }
+    v16[e] = (_Float16)(v * (double)split_scale(*amax2));
+}
+// slack[column] (see above), from the V16 just written; one wave per column
+__global__ __launch_bounds__(64) void lr_slack_kernel(const double* __restrict__ basis, const double* __restrict__ bank64,
+                                                      int K, int L, const int32_t* __restrict__ meta,
+                                                      const float* __restrict__ amax2, const _Float16* __restrict__ v16,
+                                                      float* __restrict__ slack) {
+    const int col = blockIdx.x, lane = threadIdx.x;
+    const int tile = col / CSC_TILE_COLS, c = col % CSC_TILE_COLS;
+    const int k = meta[tile * META_INTS + c];
+    if (k < 0) { if (lane == 0) slack[col] = 0.f; return; }
+    __shared__ double v[LR_R];
+    const double inv = 1.0 / (double)split_scale(*amax2);
+    if (lane < LR_R) {
+        const int i = lane, ks = i >> 5, lq = (i >> 3) & 3, j = i & 7;
+        const size_t blk = (size_t)tile * NT + c / 16;
+        v[i] = (double)v16[((blk * (LR_R / 32) + ks) * 64 + 16 * lq + (c & 15)) * 8 + j] * inv;
+    }
+    __syncthreads();
+    double rr = 0.0, vv = 0.0;
+    for (int l = lane; l < L; l += 64) {
+        double x = bank64[(size_t)k * L + l];
+        for (int i = 0; i < LR_R; ++i) x = fma(-v[i], basis[(size_t)i * L + l], x);
+        rr = fma(x, x, rr);
+    }
+    if (lane < LR_R) vv = v[lane] * v[lane];
+    rr = wave_sum(rr);
+    vv = wave_sum(vv);
+    if (lane == 63) {
+        const double rel = 4.8828125e-04 + 8.0 * (double)(L + 8) * 1.1920928955078125e-07 + 64.0 * 5.9604644775390625e-08 + 9.5367431640625e-07;
+        slack[col] = (float)((sqrt(rr) + rel * sqrt(vv)) * 1.000001 + 1e-30);
+    }
+}
+
+__global__ __launch_bounds__(WG, 2) void screen_lr_kernel(const LevelArgs a) {
+    extern __shared__ double lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int N = a.N, K = a.K, L = a.L, P = a.P, d = a.depth;
+    const int ntile = (K + CSC_TILE_COLS - 1) / CSC_TILE_COLS;
+    const int nslab = (L + SLAB - 1) / SLAB;
+    const int nunits = ntile * NG;                                    // (one row block: the host checks P <= 272)
+    const int R32 = 272 + nslab * SLAB + 8;
+    // LDS: red [4] doubles | r32 [R32] floats | slab [2][SLABF] floats, later T16 [272][LR_TS] halves | masks [nslab] |
+    // key [nunits + 1] | spick [2][8]
+    double* red = lds_raw;
+    float* r32 = reinterpret_cast<float*>(red + 4);
+    float* slab = r32 + ((R32 + 3) & ~3);
+    _Float16* t16 = reinterpret_cast<_Float16*>(slab);
+    uint32_t* masks = reinterpret_cast<uint32_t*>(slab + LR_AREA_F);
+    unsigned* key = masks + MAX_SLABS;
+    int* spick = reinterpret_cast<int*>(key + nunits + 1);
+    const int Fd = a.ts.F[d];
+    size_t s;
+    int j;
+    node_of_block(Fd, s, j);
+    const int t = a.sibling;
+    if ((long long)j + (long long)t * a.ts.pw[d] >= a.ts.F[d + 1]) return;       // the node has no child t
+    if (t > 0 && a.flags[s * Fd + j]) return;                                    // the node went to the fp32 kernel
+    if (tid < t) {
+        const size_t cid = s * a.NN + a.ts.off[d + 1] + j + (size_t)tid * a.ts.pw[d];
+        spick[tid] = a.node_pos[cid];
+        spick[CSC_MAX_CONNECTIONS + tid] = a.node_atom[cid];
+    }
+    const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
+    double v = 0.0;
+    for (int i = tid; i < N; i += WG) { const double x = rin[i]; v = fma(x, x, v); }
+    v = wave_sum(v);
+    if (lane == 63) red[wave] = v;
+    for (int u = tid; u <= nunits; u += WG) key[u] = fkey(-INFINITY);
+    if (tid < MAX_SLABS) masks[tid] = tid < nslab ? (((1u << (LR_R / 16)) - 1u) << (NT - LR_R / 16)) : 0u;
+    __syncthreads();
+    const double rnorm2 = red[0] + red[1] + red[2] + red[3];
+    const float am2 = *a.amax2, am = sqrtf(am2);
+    if (!(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 0.5e-30 && rnorm2 < 2e30)) return;   // (as screen16_kernel)
+    const double sc = 64.0 / sqrt(rnorm2);
+    for (int i = tid; i < R32; i += WG) r32[i] = i < N ? (float)(rin[i] * sc) : 0.f;
+    __syncthreads();
+    // ---- T = R U on the fp32 matrix cores: rows 0 .. 255 (corr_tile_gemm), 256 .. 271 (corr_rem_gemm) --------------------
+    {
+        // (the remainder rows first: their one accumulator per wave waits in registers while the main product runs;
+        // T16 shares the slab buffers' space and is written when both products are done -- each ends with a barrier)
+        f32x4 acc[MT][NT];
+        corr_rem_gemm(a.lr_u32, masks, nslab, r32 + CSC_TILE_ROWS + lr + lq, slab, acc);
+        f32x4 remv = acc[0][NT - 1];
+        int remni = NT - 1;
+#pragma unroll
+        for (int ni = NT - LR_R / 16; ni < NT - 1; ++ni)
+            if ((ni & 3) == wave) { remv = acc[0][ni]; remni = ni; }
+        const bool remmine = (remni & 3) == wave;
+        corr_tile_gemm(a.lr_u32, masks, nslab, r32 + 64 * wave + lr + lq, slab, acc);
+#pragma unroll
+        for (int ni = NT - LR_R / 16; ni < NT; ++ni) {
+            const int c = 16 * (ni - (NT - LR_R / 16)) + lr;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    t16[(64 * wave + 16 * mi + 4 * lq + rg) * LR_TS + c] = (_Float16)acc[mi][ni][rg];
+        }
+        if (remmine) {
+            const int c = 16 * (remni - (NT - LR_R / 16)) + lr;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) t16[(CSC_TILE_ROWS + 4 * lq + rg) * LR_TS + c] = (_Float16)remv[rg];
+        }
+    }
+    __syncthreads();
+    // ---- C~ = T V16: the 17 x 2 A fragments of the node stay in registers, every wave takes the 16-column blocks
+    // b = w, w + 4, ... with their two B fragments straight from L2, one block ahead ---------------------------------------
+    f16x8 A[17][LR_R / 32];
+#pragma unroll
+    for (int rt = 0; rt < 17; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < LR_R / 32; ++ks)
+            A[rt][ks] = *reinterpret_cast<const f16x8*>(t16 + (16 * rt + lr) * LR_TS + 32 * ks + 8 * lq);
+    const int nblk = ntile * NT, npad = ntile * CSC_TILE_COLS - K;
+    const float toacc = 64.f * split_scale(am2);                      // units of ||r|| -> accumulator units
+    const float e1 = (9.765625e-4f + 6.103515625e-05f + 1e-6f) * am + 2.98023223876953125e-08f * sqrtf((float)L) * (1.f + am);
+    const int rows = min(P, 272);
+    float lbmax = -INFINITY;
+    f16x8 Bc[LR_R / 32], Bn[LR_R / 32];
+    if (wave < nblk) {
+#pragma unroll
+        for (int ks = 0; ks < LR_R / 32; ++ks)
+            Bc[ks] = *reinterpret_cast<const f16x8*>(a.lr_v16 + ((size_t)wave * (LR_R / 32) + ks) * 512 + lane * 8);
+    }
+    for (int b = wave; b < nblk; b += 4) {
+        const int bn = min(b + 4, nblk - 1);                           // (the last block again: the load count stays fixed)
+#pragma unroll
+        for (int ks = 0; ks < LR_R / 32; ++ks)
+            Bn[ks] = *reinterpret_cast<const f16x8*>(a.lr_v16 + ((size_t)bn * (LR_R / 32) + ks) * 512 + lane * 8);
+        f32x4 acc[17];
+#pragma unroll
+        for (int rt = 0; rt < 17; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt][0], Bc[0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int ks = 1; ks < LR_R / 32; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 17; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt][ks], Bc[ks], acc[rt], 0, 0, 0);
+        const int tile = b / NT, blk = b - tile * NT;
+        const bool colok = tile * CSC_TILE_COLS + 16 * blk + lr >= npad;
+        const float slk = a.lr_slack[tile * CSC_TILE_COLS + 16 * blk + lr] * toacc;
+        // lower bound of the node's maximum: this lane's largest entry (before suppression: a suppressed entry counts 0,
+        // which the bound below covers as well) minus the column's slack
+        float lo = -INFINITY, hi = -INFINITY;
+#pragma unroll
+        for (int rt = 0; rt < 17; ++rt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const bool in = 16 * rt + 4 * lq + rg < rows;
+                lo = fmaxf(lo, in ? acc[rt][rg] : -INFINITY);
+            }
+        hi = lo;
+        if (t > 0 && colok) {
+            // a later sibling: entries similar to an earlier pick take the value 0 (as in screen_blocks16)
+            const int atom = a.meta[(size_t)tile * META_INTS + 16 * blk + lr];
+            const int Wd = a.W;
+            bool any = false;
+            for (int q = 0; q < t; ++q) {
+                const uint32_t* srow = a.sim_bits + ((size_t)spick[CSC_MAX_CONNECTIONS + q] * K + atom) * Wd;
+                const int dpb = 4 * lq - spick[q] + P - 1;
+                const int w0 = dpb >> 5, b0 = dpb & 31;
+                uint32_t wd[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) wd[i] = srow[min(w0 + i, Wd - 1)];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) wd[i] = __funnelshift_r(wd[i], wd[i + 1], b0);
+#pragma unroll
+                for (int rt = 0; rt < 17; ++rt)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        if ((wd[rt >> 1] >> (16 * (rt & 1) + rg)) & 1u) { acc[rt][rg] = 0.f; any = true; }
+            }
+            if (any) {
+                hi = -INFINITY;
+#pragma unroll
+                for (int rt = 0; rt < 17; ++rt)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        hi = fmaxf(hi, 16 * rt + 4 * lq + rg < rows ? acc[rt][rg] : -INFINITY);
+                lo = fminf(lo, hi);                                   // (the unsuppressed maximum is no lower bound any more)
+            }
+        }
+        // upper bound of the block: largest (suppressed) entry + slack - e1; lower bound: - slack.  A NaN gives +inf / -inf.
+        float ub = hi + slk - e1 * toacc, lb = lo - slk;
+        if (!(ub == ub)) ub = INFINITY;
+        if (!(lb == lb)) lb = -INFINITY;
+        ub = wave_max(colok ? ub : -INFINITY);
+        lbmax = fmaxf(lbmax, colok ? lb : -INFINITY);
+        if (lane == 63) atomicMax(&key[blk / NG + NG * tile], fkey(ub));
+#pragma unroll
+        for (int ks = 0; ks < LR_R / 32; ++ks) Bc[ks] = Bn[ks];
+    }
+    lbmax = wave_max(lbmax);
+    if (lane == 63) atomicMax(&key[nunits], fkey(lbmax));
     __syncthreads();
     float* tab = screen_table(a, s, j, d, t);
-    for (int u = tid; u < nunits; u += WG) tab[u] = fkey_inv(key[u]);
+    for (int u = tid; u <= nunits; u += WG) tab[u] = fkey_inv(key[u]);
 }
 
 __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArgs a) {
@@ -3873,6 +4151,22 @@ static const _Float16* bank_tiles16s(const float* d_bank32t, int K, int L, int l
     const double* end = bank_anorm2(d_bank32t, K, L) + K + (K & 1);          // 16-byte aligned
     return reinterpret_cast<const _Float16*>(end) + (lo ? tile_floats(K, L) : 0);
 }
+// behind the scaled tiles, for dictionaries of more than one bank tile: the low-rank section (csc_bank_lowrank):
+// [basis as one fp32 tile: n_slabs * SLABF floats][V16: n_tiles * 9 * (LR_R / 32) * 512 halves][slack: n_tiles * 144 floats]
+static size_t bank_base_elems(int K, int L) {
+    return bank16_offset(K, L) + tile_floats(K, L) / 2 + 16 + 2 * (size_t)(K + (K & 1)) + tile_floats(K, L);
+}
+static size_t bank_lr_elems(int K, int L) {
+    if (K <= CSC_TILE_COLS) return 0;
+    return (size_t)n_slabs(L) * SLABF + (size_t)n_tiles(K) * NT * (LR_R / 32) * 256 + (size_t)n_tiles(K) * CSC_TILE_COLS;
+}
+static float* bank_lr_u32(const float* d_bank32t, int K, int L) { return const_cast<float*>(d_bank32t) + bank_base_elems(K, L); }
+static _Float16* bank_lr_v16(const float* d_bank32t, int K, int L) {
+    return reinterpret_cast<_Float16*>(bank_lr_u32(d_bank32t, K, L) + (size_t)n_slabs(L) * SLABF);
+}
+static float* bank_lr_slack(const float* d_bank32t, int K, int L) {
+    return bank_lr_u32(d_bank32t, K, L) + (size_t)n_slabs(L) * SLABF + (size_t)n_tiles(K) * NT * (LR_R / 32) * 256;
+}
 static const int32_t* bank_meta(const float* d_bank32t, int K, int L) {
     return reinterpret_cast<const int32_t*>(d_bank32t + tile_floats(K, L));
 }
@@ -3932,7 +4226,29 @@ const char* csc_last_error(void) { return g_err; }
 
 size_t csc_bank32_elems(int K, int L) {
     if (K <= 0 || L <= 0) return 0;
-    return bank16_offset(K, L) + tile_floats(K, L) / 2 + 16 + 2 * (size_t)(K + (K & 1)) + tile_floats(K, L);
+    return bank_base_elems(K, L) + bank_lr_elems(K, L);
+}
+
+int csc_lowrank_rank(void) { return LR_R; }
+
+int csc_bank_lowrank(float* d_bank32t, const double* d_bank64, int K, int L, const double* d_basis, int rank, void* stream) {
+    if (!d_bank32t || !d_bank64 || !d_basis || K <= 0 || L <= 0) FAIL(-1, "csc_bank_lowrank: bad arguments");
+    if (rank != LR_R) FAIL(-13, "csc_bank_lowrank: the screen takes a basis of %d vectors, not %d", LR_R, rank);
+    if (K <= CSC_TILE_COLS) FAIL(-13, "csc_bank_lowrank: dictionaries of one bank tile (K <= %d) have no low-rank screen", CSC_TILE_COLS);
+    if (n_slabs(L) > MAX_SLABS) FAIL(-8, "atom length %d exceeds %d", L, MAX_SLABS * SLAB);
+    hipStream_t st = (hipStream_t)stream;
+    const int nslab = n_slabs(L), ntile = n_tiles(K);
+    clear_stale_error();
+    const size_t nu = (size_t)nslab * SLABF;
+    hipLaunchKernelGGL(lr_pack_u_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, d_basis, L, nslab,
+                       bank_lr_u32(d_bank32t, K, L));
+    const size_t nv = (size_t)ntile * NT * (LR_R / 32) * 512;
+    hipLaunchKernelGGL(lr_pack_v_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, d_basis, d_bank64, K, L,
+                       bank_meta(d_bank32t, K, L), bank_amax2(d_bank32t, K, L), bank_lr_v16(d_bank32t, K, L), nv);
+    hipLaunchKernelGGL(lr_slack_kernel, dim3((unsigned)(ntile * CSC_TILE_COLS)), dim3(64), 0, st, d_basis, d_bank64, K, L,
+                       bank_meta(d_bank32t, K, L), bank_amax2(d_bank32t, K, L), bank_lr_v16(d_bank32t, K, L),
+                       bank_lr_slack(d_bank32t, K, L));
+    return launch_status("csc_bank_lowrank kernels");
 }
 
 int csc_sim_words(int N, int L) {
@@ -4120,14 +4436,19 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
     const int nrb16 = (nrb > 1 && P - (nrb - 1) * CSC_TILE_ROWS <= 16) ? nrb - 1 : nrb;
     const size_t units16 = (size_t)n_tiles(K) * nrb16 * NG;
     const size_t lds_screen = 4 * 8 + (size_t)R16_COPIES * r16t_stride(P, Lp) * 2 + (size_t)TRING * TG_BLK * 2 + units16 * 4 +
-                              (((size_t)n_tiles(K) * NT * 2 + 15) & ~(size_t)15) + 2 * CSC_MAX_CONNECTIONS * 4;
+                              (((size_t)n_tiles(K) * NT * 2 + 15) & ~(size_t)15) + 2 * CSC_MAX_CONNECTIONS * 4 + ((units16 + 15) & ~(size_t)15);
+    const size_t lds_lr = 32 + (size_t)ceil4(272 + Lp + 8) * 4 + (size_t)LR_AREA_F * 4 + MAX_SLABS * 4 + (units16 + 1) * 4 +
+                          2 * CSC_MAX_CONNECTIONS * 4;
     const bool tiled16 = tiled && !(flags & CSC_FLAG_FP32_ONLY) && node_flags && mode == 0 && L <= 682 &&
                          lds16 <= 150 * 1024 && (long long)n_tiles(K) * nrb * NG <= MAX_UNITS16 && n_tiles(K) * NT <= 2 * MAX_UNITS16 &&
-                         lds_screen <= 100 * 1024 && units16 * 4 <= (size_t)(N + TRI(max_sparsity) + max_sparsity) * 8;
+                         lds_screen <= 100 * 1024 && (units16 + 1) * 4 <= (size_t)(N + TRI(max_sparsity) + max_sparsity) * 8;
     clear_stale_error();
+    // the low-rank screen in front (the caller vouches for an installed section: csc_bank_lowrank): one row block only
+    const bool lowrank = tiled16 && (flags & CSC_FLAG_LOWRANK) && P <= 272 && lds_lr <= 80 * 1024;
     if (tiled16) {
         hipFuncSetAttribute((const void*)mmp_level_tiled16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
         hipFuncSetAttribute((const void*)screen16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_screen);
+        if (lowrank) hipFuncSetAttribute((const void*)screen_lr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lr);
     }
     hipFuncSetAttribute(tiled ? (const void*)mmp_level_tiled_kernel : (const void*)mmp_level_kernel,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -4157,6 +4478,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         const int span = timer_begin(st, d);
         a.flags = nullptr; a.S = S; a.signals = d_signals; a.ws[0] = ws[0]; a.ws[1] = ws[1];
         a.picks_only = 0; a.from_root = 0; a.sibling = -1;
+        a.lr_u32 = nullptr; a.lr_v16 = nullptr; a.lr_slack = nullptr;
         // level 0 in front of the chain kernel (every node of level 1 has one child): it only has to pick -- the chain
         // kernel builds a pick's node from the signal, so no child residual crosses HBM between the two launches
         const bool root_picks = lean && mode == 0 && d == 0 && max_sparsity > 1 && connections > 1 && ts.pw[1] >= ts.F[2];
@@ -4170,8 +4492,12 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
             int nsib = 0;
             for (int r = 0; r < connections; ++r)
                 if ((long long)r * ts.pw[d] < ts.F[d + 1]) ++nsib;
+            a.lr_u32 = lowrank ? bank_lr_u32(d_bank32t, K, L) : nullptr;
+            a.lr_v16 = lowrank ? bank_lr_v16(d_bank32t, K, L) : nullptr;
+            a.lr_slack = lowrank ? bank_lr_slack(d_bank32t, K, L) : nullptr;
             for (int t = 0; t < nsib; ++t) {
                 a.sibling = t;
+                if (lowrank) hipLaunchKernelGGL(screen_lr_kernel, dim3((unsigned)grid), dim3(WG), lds_lr, st, a);
                 hipLaunchKernelGGL(screen16_kernel, dim3((unsigned)grid), dim3(WG), lds_screen, st, a);
                 hipLaunchKernelGGL(mmp_level_tiled16_kernel, dim3((unsigned)grid), dim3(WG), lds16, st, a);
             }

@@ -140,6 +140,21 @@ class DeviceBank:
             self.bank32t = torch.empty(n32, dtype=torch.float32, device=self.device)
             _lib.check(self.lib.csc_bank_pack(_ptr(self.bank64), self.K, self.L, _ptr(self.bank32t),
                                               _stream(self.device)), "csc_bank_pack")
+            # dictionaries of more than one bank tile: the low-rank section of the image (csc_bank_lowrank) from the leading
+            # eigenvectors of the bank's Gram matrix -- any orthonormal basis is valid, the library computes its bounds
+            # from the basis it is given; this one is the best of its size.  (Gram product on the device, the small
+            # symmetric eigenproblem on the host.)
+            self.lowrank = False
+            if self.K > _lib.TILE_COLS:
+                r = self.lib.csc_lowrank_rank()
+                if self.L >= r:
+                    gram = (self.bank64.T @ self.bank64).cpu().numpy()
+                    _, vec = np.linalg.eigh(gram)                       # ascending eigenvalues
+                    basis = np.ascontiguousarray(vec[:, ::-1][:, :r].T)  # [r][L], orthonormal rows
+                    self._basis = torch.from_numpy(basis).to(self.device)
+                    _lib.check(self.lib.csc_bank_lowrank(_ptr(self.bank32t), _ptr(self.bank64), self.K, self.L,
+                                                         _ptr(self._basis), r, _stream(self.device)), "csc_bank_lowrank")
+                    self.lowrank = True                              # set to False to screen in full (same results)
         self._sim = {}
         # correlations on the fp16 matrix cores as a filter in front of the float64 re-score (same results);
         # set to True to correlate in fp32 only (CSC_FLAG_FP32_ONLY)
@@ -325,7 +340,8 @@ class DeviceBank:
                     "rec_sel": rec[:, 16 * K:].view(torch.int32).unflatten(1, (K, K, 2)),
                     "stats": torch.zeros(4, dtype=torch.int32, device=dev),
                 }
-            flags = (1 if self.fp32_only else 0) | (0 if self.lean else 2) | 4        # 4 = CSC_FLAG_RECORDS_AOS
+            flags = ((1 if self.fp32_only else 0) | (0 if self.lean else 2) | 4        # 4 = CSC_FLAG_RECORDS_AOS
+                     | (8 if self.lowrank else 0))                                 # 8 = CSC_FLAG_LOWRANK
             tail = (_ptr(out["node_pos"]), _ptr(out["node_atom"]), _ptr(out["node_mse"]), _ptr(out["node_coef"]),
                     _ptr(out["rec_buf"]), None, None, _ptr(out["stats"]), _stream(dev))
             head = (_ptr(self.bank32t), _ptr(self.bank64), _ptr(sim), self.K, self.L, _ptr(sig), S, N,

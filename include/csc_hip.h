@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CSC_ABI_VERSION 6
+#define CSC_ABI_VERSION 7
 #define CSC_TILE_COLS 144      /* atoms per column tile of the correlation kernel (9 x 16)   */
 #define CSC_TILE_ROWS 256      /* positions per row tile (4 waves x 4 x 16)                   */
 #define CSC_MAX_SPARSITY 16    /* largest tree depth / support size                           */
@@ -34,6 +34,7 @@ extern "C" {
 #define CSC_FLAG_FP32_ONLY 1   /* csc_mmpdf_batch flags: skip the fp16 matrix-core filter      */
 #define CSC_FLAG_NO_LEAN 2     /* keep single-child levels on the register-resident kernel      */
 #define CSC_FLAG_RECORDS_AOS 4 /* per-sparsity records as one contiguous record per signal      */
+#define CSC_FLAG_LOWRANK 8     /* the bank image holds a low-rank section (csc_bank_lowrank)     */
 #define CSC_STATIC_SCRATCH_BYTES (64u << 20)   /* static device scratch of csc_mmpdf_batch_static      */
 
 int csc_abi_version(void);
@@ -51,6 +52,17 @@ int    csc_sim_words(int N, int L);             /* uint32 per (k_sel, k) row of 
  *             that all-zero blocks can be skipped), the column permutation and block masks, the same blocks
  *             in fp16 and max_k ||a_k||^2. */
 int csc_bank_pack(const double* d_bank64, int K, int L, float* d_bank32t, void* stream);
+
+/* Low-rank screen of large dictionaries (K > 144; no counterpart in the reference, whose correlations are one FFT
+ * convolution per atom, src/csc/dictionary.py:395-407).  d_basis: [rank][L] f64, ORTHONORMAL vectors (any basis: e.g.
+ * the leading eigenvectors of the bank's Gram matrix B^T B); rank must equal csc_lowrank_rank().  Fills the low-rank
+ * section of the packed bank (csc_bank32_elems reserves it when K > 144): the basis as an fp32 tile, the atoms'
+ * coefficients in fp16 and, per atom, the rigorous bound of what the rank-`rank` product can miss of a correlation.
+ * csc_mmpdf_batch with CSC_FLAG_LOWRANK then screens a node's correlations through the basis first (34 matrix
+ * instructions per 16 atoms instead of ~190) and multiplies in full only the tenth of the dictionary that bound cannot
+ * exclude; results are identical with or without it. */
+int csc_lowrank_rank(void);
+int csc_bank_lowrank(float* d_bank32t, const double* d_bank64, int K, int L, const double* d_basis, int rank, void* stream);
 
 /* Atom-vs-dictionary similarity table.  Replaces, for every node, the
  * computeCorrelations(atom_signal)/||atom_signal|| <= thr mask of src/csc/mmp.py:92-93,196-201:

@@ -1,5 +1,5 @@
 """BASELINE.json config 3 alone (9570-atom dictionary, c3/B3/K5), for profiling:
-    python3 scripts/run_config3.py [signals] [reps] [--fp32]
+    python3 scripts/run_config3.py [signals] [reps] [--fp32] [--no-lowrank]
 prints one JSON line with the throughput; under rocprofv3 the kernels of the timed calls are what is traced."""
 import json
 import sys
@@ -19,6 +19,8 @@ np.random.seed(3)
 sigs = np.array([large.generateConstrainedTestSignal(777, 4, 10, 10, 0.75)[0] for _ in range(n)])
 bank = large.device_bank()
 bank.fp32_only = "--fp32" in sys.argv
+if "--no-lowrank" in sys.argv:
+    bank.lowrank = False
 d = torch.from_numpy(sigs).cuda()
 out = bank.mmpdf_launch(d, 5, 3, 3, 0.8, want_coef=False)
 torch.cuda.synchronize()
@@ -27,5 +29,5 @@ for _ in range(reps):
     bank.mmpdf_launch(d, 5, 3, 3, 0.8, want_coef=False, out=out)
 torch.cuda.synchronize()
 dt = (time.time() - t0) / reps
-print(json.dumps({"config": "3", "signals": n, "fp32_only": bank.fp32_only, "seconds": dt, "signals_per_s": n / dt,
+print(json.dumps({"config": "3", "signals": n, "fp32_only": bank.fp32_only, "lowrank": bank.lowrank, "seconds": dt, "signals_per_s": n / dt,
                   "stats": out["stats"].cpu().tolist()}))

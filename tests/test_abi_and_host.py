@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.EXPORTS) == names
-    assert lib.csc_abi_version() == 6
+    assert lib.csc_abi_version() == 7
 
 
 def test_header_cites_reference_for_every_entry_point():
