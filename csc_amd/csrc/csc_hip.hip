@@ -1693,6 +1693,16 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// The compiler counts the wait states between an MFMA and the first instruction that reads its result, but it does not
+// look inside asm statements: a vmax3 scheduled right behind the MFMA that feeds it reads the register before the
+// matrix core has written it (seen in screen_lr_kernel: bounds that changed from run to run).  Accumulators that go to
+// vmax3 pass through here first: 16 wait states (a 16x16x32 product needs 11), tied to the registers so that neither the
+// products nor the vmax3 chain can move across.
+__device__ __forceinline__ void mfma_settle(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, f32x4& a4, f32x4& a5, f32x4& a6,
+                                            f32x4& a7) {
+    asm volatile("s_nop 15" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+}
+__device__ __forceinline__ void mfma_settle(f32x4& a0) { asm volatile("s_nop 15" : "+v"(a0)); }
 
 // The node's tasks, built by 9 + 18 threads: (1) thread c < 9: live slab range of column tile c from the bank's block
 // masks (global: no wait for the LDS copy); (2) behind a barrier, thread t < 18 = (tile, row half): the tile's rank by
@@ -1803,6 +1813,7 @@ __device__ __forceinline__ void chain_product16(const _Float16* __restrict__ ban
                 }
         }
         // the lane's maximum: two chains of v_max3_f32 (NaN operands are skipped, like fmaxf)
+        mfma_settle(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
         float m0 = vmax3(acc[0][0], acc[0][1], acc[0][2]), m1 = vmax3(acc[0][3], acc[1][0], acc[1][1]);
         m0 = vmax3(m0, acc[1][2], acc[1][3]); m1 = vmax3(m1, acc[2][0], acc[2][1]);
         m0 = vmax3(m0, acc[2][2], acc[2][3]); m1 = vmax3(m1, acc[3][0], acc[3][1]);
@@ -3330,7 +3341,11 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
         const float lb = tab[nunits];
         for (int u = tid; u < nunits; u += WG) {
             const float ub = tab[u];
+#ifdef CSC_LR_CHECK
+            const bool skip = false;
+#else
             const bool skip = ub + (e1 + 0.5f * band) * toacc < lb - 2.5f * band * toacc;     // (false on NaN: multiplied)
+#endif
             nd[u] = skip ? 0 : 1;
             if (skip) key[u] = fkey(ub);
         }
@@ -3340,6 +3355,22 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
     if (rem) screen_blocks16<true>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring, t, spick, need);
     else screen_blocks16<false>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring, t, spick, need);
     __syncthreads();
+#ifdef CSC_LR_CHECK
+    if (a.lr_u32) {
+        // development aid: every unit multiplied; its single-term maximum against the low-rank bounds
+        const float am = sqrtf(am2);
+        const float toacc = 64.f * split_scale(am2);
+        const float e1 = (9.765625e-4f + 6.103515625e-05f + 1e-6f) * am + 2.98023223876953125e-08f * sqrtf((float)L) * (1.f + am);
+        float mx = -INFINITY;
+        for (int u = 0; u < nunits; ++u) mx = fmaxf(mx, fkey_inv(key[u]));
+        for (int u = tid; u < nunits; u += WG) {
+            const float got = fkey_inv(key[u]), ub = tab[u];
+            if (got > ub + 2.f * e1 * toacc) printf("LRCHK ub: s %d j %d d %d t %d unit %d single %g bound %g (e1 %g)\n", (int)s, j, d, t, u, got, ub, e1 * toacc);
+        }
+        if (tid == 0 && mx < tab[nunits] - e1 * toacc) printf("LRCHK lb: s %d j %d d %d t %d max %g lb %g\n", (int)s, j, d, t, mx, tab[nunits]);
+    }
+    __syncthreads();
+#endif
     for (int u = tid; u < nunits; u += WG) tab[u] = fkey_inv(key[u]);
 }
 
@@ -3424,7 +3455,7 @@ __global__ __launch_bounds__(64) void lr_slack_kernel(const double* __restrict__
     }
 }
 
-__global__ __launch_bounds__(WG, 2) void screen_lr_kernel(const LevelArgs a) {
+__global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
     extern __shared__ double lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -3469,6 +3500,13 @@ __global__ __launch_bounds__(WG, 2) void screen_lr_kernel(const LevelArgs a) {
     const double sc = 64.0 / sqrt(rnorm2);
     for (int i = tid; i < R32; i += WG) r32[i] = i < N ? (float)(rin[i] * sc) : 0.f;
     __syncthreads();
+#ifdef CSC_PHASE_PROF
+    unsigned long long lr_t = __builtin_readcyclecounter();
+#define LR_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); \
+        atomicAdd(&g_prof[i][blockIdx.x % PROF_BUCKETS], n_ - lr_t); lr_t = n_; } } while (0)
+#else
+#define LR_STAMP(i)
+#endif
     // ---- T = R U on the fp32 matrix cores: rows 0 .. 255 (corr_tile_gemm), 256 .. 271 (corr_rem_gemm) --------------------
     {
         // (the remainder rows first: their one accumulator per wave waits in registers while the main product runs;
@@ -3498,50 +3536,67 @@ __global__ __launch_bounds__(WG, 2) void screen_lr_kernel(const LevelArgs a) {
         }
     }
     __syncthreads();
-    // ---- C~ = T V16: the 17 x 2 A fragments of the node stay in registers, every wave takes the 16-column blocks
-    // b = w, w + 4, ... with their two B fragments straight from L2, one block ahead ---------------------------------------
-    f16x8 A[17][LR_R / 32];
+    LR_STAMP(29);
+    // ---- C~ = T V16.  Two waves share a block's rows -- wave w takes row tiles 0 .. 8 (w even) or 9 .. 16 (w odd) of the
+    // blocks b = (w >> 1), + 2, + 4, ...: 9 x 2 A fragments stay in registers (72 VGPRs; all 17 x 2 with their 68
+    // accumulators spilled at 256 registers, and every reload drained the fragments in flight), three workgroups per CU.
+    // B fragments (and the block's slack, one float per lane: the lane's column) come straight from L2, two blocks ahead,
+    // in three buffers in turn ----------------------------------------------------------------------------------------
+    const int half = wave & 1, rt0 = 9 * half;                         // row tiles rt0 .. rt0 + 8 (the second half: 8 tiles)
+    f16x8 A[9][LR_R / 32];
 #pragma unroll
-    for (int rt = 0; rt < 17; ++rt)
+    for (int i = 0; i < 9; ++i)
 #pragma unroll
         for (int ks = 0; ks < LR_R / 32; ++ks)
-            A[rt][ks] = *reinterpret_cast<const f16x8*>(t16 + (16 * rt + lr) * LR_TS + 32 * ks + 8 * lq);
+            A[i][ks] = *reinterpret_cast<const f16x8*>(t16 + (16 * min(rt0 + i, 16) + lr) * LR_TS + 32 * ks + 8 * lq);
     const int nblk = ntile * NT, npad = ntile * CSC_TILE_COLS - K;
     const float toacc = 64.f * split_scale(am2);                      // units of ||r|| -> accumulator units
     const float e1 = (9.765625e-4f + 6.103515625e-05f + 1e-6f) * am + 2.98023223876953125e-08f * sqrtf((float)L) * (1.f + am);
     const int rows = min(P, 272);
     float lbmax = -INFINITY;
-    f16x8 Bc[LR_R / 32], Bn[LR_R / 32];
-    if (wave < nblk) {
+    f16x8 B0[LR_R / 32], B1[LR_R / 32], B2[LR_R / 32];
+    float S0, S1, S2;
+    auto load_b = [&](f16x8 (&Bx)[LR_R / 32], float& Sx, int b) __attribute__((always_inline)) {
+        const int bb = min(b, nblk - 1);                               // (past the end: the last block again, unused)
 #pragma unroll
         for (int ks = 0; ks < LR_R / 32; ++ks)
-            Bc[ks] = *reinterpret_cast<const f16x8*>(a.lr_v16 + ((size_t)wave * (LR_R / 32) + ks) * 512 + lane * 8);
-    }
-    for (int b = wave; b < nblk; b += 4) {
-        const int bn = min(b + 4, nblk - 1);                           // (the last block again: the load count stays fixed)
+            Bx[ks] = *reinterpret_cast<const f16x8*>(a.lr_v16 + ((size_t)bb * (LR_R / 32) + ks) * 512 + lane * 8);
+        Sx = a.lr_slack[16 * bb + lr];                                 // (column 144 tile + 16 blk + lr = 16 b + lr)
+    };
+    auto block = [&](const f16x8 (&Bcur)[LR_R / 32], float Scur, int b) __attribute__((always_inline)) {
+        f32x4 acc[9];
 #pragma unroll
-        for (int ks = 0; ks < LR_R / 32; ++ks)
-            Bn[ks] = *reinterpret_cast<const f16x8*>(a.lr_v16 + ((size_t)bn * (LR_R / 32) + ks) * 512 + lane * 8);
-        f32x4 acc[17];
-#pragma unroll
-        for (int rt = 0; rt < 17; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt][0], Bc[0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        for (int i = 0; i < 9; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[i][0], Bcur[0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
         for (int ks = 1; ks < LR_R / 32; ++ks)
 #pragma unroll
-            for (int rt = 0; rt < 17; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt][ks], Bc[ks], acc[rt], 0, 0, 0);
+            for (int i = 0; i < 9; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[i][ks], Bcur[ks], acc[i], 0, 0, 0);
         const int tile = b / NT, blk = b - tile * NT;
         const bool colok = tile * CSC_TILE_COLS + 16 * blk + lr >= npad;
-        const float slk = a.lr_slack[tile * CSC_TILE_COLS + 16 * blk + lr] * toacc;
-        // lower bound of the node's maximum: this lane's largest entry (before suppression: a suppressed entry counts 0,
-        // which the bound below covers as well) minus the column's slack
-        float lo = -INFINITY, hi = -INFINITY;
+        const float slk = Scur * toacc;
+        mfma_settle(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
+        mfma_settle(acc[8]);
+        // the lane's maximum over its valid rows: the first half's nine row tiles are all inside (the host takes this kernel
+        // for 256 <= P <= 272 only); in the second half slot 7 is the remainder tile (rows 256 ..) and slot 8 a repeat of it
+        auto lane_max = [&]() __attribute__((always_inline)) -> float {
+            float m0 = vmax3(acc[0][0], acc[0][1], acc[0][2]), m1 = vmax3(acc[0][3], acc[1][0], acc[1][1]);
+            m0 = vmax3(m0, acc[1][2], acc[1][3]); m1 = vmax3(m1, acc[2][0], acc[2][1]);
+            m0 = vmax3(m0, acc[2][2], acc[2][3]); m1 = vmax3(m1, acc[3][0], acc[3][1]);
+            m0 = vmax3(m0, acc[3][2], acc[3][3]); m1 = vmax3(m1, acc[4][0], acc[4][1]);
+            m0 = vmax3(m0, acc[4][2], acc[4][3]); m1 = vmax3(m1, acc[5][0], acc[5][1]);
+            m0 = vmax3(m0, acc[5][2], acc[5][3]); m1 = vmax3(m1, acc[6][0], acc[6][1]);
+            m0 = vmax3(m0, acc[6][2], acc[6][3]);
+            float m = fmaxf(m0, m1);
+            if (half == 0) {                                          // (uniform)
+                m0 = vmax3(acc[7][0], acc[7][1], acc[7][2]); m1 = vmax3(acc[7][3], acc[8][0], acc[8][1]);
+                m = fmaxf(m, vmax3(m0, m1, fmaxf(acc[8][2], acc[8][3])));
+            } else {
 #pragma unroll
-        for (int rt = 0; rt < 17; ++rt)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const bool in = 16 * rt + 4 * lq + rg < rows;
-                lo = fmaxf(lo, in ? acc[rt][rg] : -INFINITY);
+                for (int rg = 0; rg < 4; ++rg) m = fmaxf(m, CSC_TILE_ROWS + 4 * lq + rg < rows ? acc[7][rg] : -INFINITY);
             }
+            return m;
+        };
+        float lo = lane_max(), hi;
         hi = lo;
         if (t > 0 && colok) {
             // a later sibling: entries similar to an earlier pick take the value 0 (as in screen_blocks16)
@@ -3550,26 +3605,21 @@ __global__ __launch_bounds__(WG, 2) void screen_lr_kernel(const LevelArgs a) {
             bool any = false;
             for (int q = 0; q < t; ++q) {
                 const uint32_t* srow = a.sim_bits + ((size_t)spick[CSC_MAX_CONNECTIONS + q] * K + atom) * Wd;
-                const int dpb = 4 * lq - spick[q] + P - 1;
+                const int dpb = 144 * half + 4 * lq - spick[q] + P - 1;      // bit of (slot 0, rg 0) of this half; >= 0
                 const int w0 = dpb >> 5, b0 = dpb & 31;
-                uint32_t wd[10];
+                uint32_t wd[6];
 #pragma unroll
-                for (int i = 0; i < 10; ++i) wd[i] = srow[min(w0 + i, Wd - 1)];
+                for (int i = 0; i < 6; ++i) wd[i] = srow[min(w0 + i, Wd - 1)];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) wd[i] = __funnelshift_r(wd[i], wd[i + 1], b0);
+                for (int i = 0; i < 5; ++i) wd[i] = __funnelshift_r(wd[i], wd[i + 1], b0);
 #pragma unroll
-                for (int rt = 0; rt < 17; ++rt)
+                for (int i = 0; i < 9; ++i)
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg)
-                        if ((wd[rt >> 1] >> (16 * (rt & 1) + rg)) & 1u) { acc[rt][rg] = 0.f; any = true; }
+                        if ((wd[i >> 1] >> (16 * (i & 1) + rg)) & 1u) { acc[i][rg] = 0.f; any = true; }
             }
             if (any) {
-                hi = -INFINITY;
-#pragma unroll
-                for (int rt = 0; rt < 17; ++rt)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg)
-                        hi = fmaxf(hi, 16 * rt + 4 * lq + rg < rows ? acc[rt][rg] : -INFINITY);
+                hi = lane_max();
                 lo = fminf(lo, hi);                                   // (the unsuppressed maximum is no lower bound any more)
             }
         }
@@ -3580,11 +3630,21 @@ __global__ __launch_bounds__(WG, 2) void screen_lr_kernel(const LevelArgs a) {
         ub = wave_max(colok ? ub : -INFINITY);
         lbmax = fmaxf(lbmax, colok ? lb : -INFINITY);
         if (lane == 63) atomicMax(&key[blk / NG + NG * tile], fkey(ub));
-#pragma unroll
-        for (int ks = 0; ks < LR_R / 32; ++ks) Bc[ks] = Bn[ks];
+    };
+    const int bfirst = wave >> 1;
+    load_b(B0, S0, bfirst);
+    load_b(B1, S1, bfirst + 2);
+    for (int b = bfirst; b < nblk; b += 6) {
+        load_b(B2, S2, b + 4);
+        block(B0, S0, b);
+        load_b(B0, S0, b + 6);
+        if (b + 2 < nblk) block(B1, S1, b + 2);
+        load_b(B1, S1, b + 8);
+        if (b + 4 < nblk) block(B2, S2, b + 4);
     }
     lbmax = wave_max(lbmax);
     if (lane == 63) atomicMax(&key[nunits], fkey(lbmax));
+    LR_STAMP(30);
     __syncthreads();
     float* tab = screen_table(a, s, j, d, t);
     for (int u = tid; u <= nunits; u += WG) tab[u] = fkey_inv(key[u]);
@@ -4444,7 +4504,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
                          lds_screen <= 100 * 1024 && (units16 + 1) * 4 <= (size_t)(N + TRI(max_sparsity) + max_sparsity) * 8;
     clear_stale_error();
     // the low-rank screen in front (the caller vouches for an installed section: csc_bank_lowrank): one row block only
-    const bool lowrank = tiled16 && (flags & CSC_FLAG_LOWRANK) && P <= 272 && lds_lr <= 80 * 1024;
+    const bool lowrank = tiled16 && (flags & CSC_FLAG_LOWRANK) && P >= CSC_TILE_ROWS && P <= 272 && lds_lr <= 80 * 1024;
     if (tiled16) {
         hipFuncSetAttribute((const void*)mmp_level_tiled16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
         hipFuncSetAttribute((const void*)screen16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_screen);
