@@ -41,7 +41,7 @@ def lib():
             "csc_similarity_table_packed": (i32, [vp, vp, i32, i32, i32, dbl, vp, vp]),
             "csc_lowrank_rank": (i32, []),
             "csc_bank_lowrank": (i32, [vp, vp, i32, i32, vp, i32, vp]),
-            "csc_bank_simunits": (i32, [vp, i32, i32, vp, i32, vp]),
+            "csc_bank_simatoms": (i32, [vp, i32, i32, vp, i32, vp]),
             "csc_correlate": (i32, [vp, i32, i32, vp, i32, i32, vp, vp]),
             "csc_correlate64": (i32, [vp, i32, i32, vp, i32, i32, vp, vp]),
             "csc_tree_nodes": (i32, [i32, i32, i32, C.POINTER(i32)]),
@@ -76,7 +76,7 @@ def lib():
 
 
 EXPORTS = ("csc_abi_version", "csc_last_error", "csc_bank32_elems", "csc_sim_words", "csc_bank_pack",
-           "csc_similarity_table", "csc_similarity_table_packed", "csc_lowrank_rank", "csc_bank_lowrank", "csc_bank_simunits", "csc_correlate", "csc_correlate64", "csc_tree_nodes", "csc_mmpdf_workspace_bytes",
+           "csc_similarity_table", "csc_similarity_table_packed", "csc_lowrank_rank", "csc_bank_lowrank", "csc_bank_simatoms", "csc_correlate", "csc_correlate64", "csc_tree_nodes", "csc_mmpdf_workspace_bytes",
            "csc_mmpdf_batch", "csc_mmpdf_batch_static", "csc_static_scratch_bytes", "csc_filter_product",
            "csc_mp_batch", "csc_project_batch", "csc_match_batch", "csc_timer_create", "csc_timer_destroy", "csc_timer_attach",
            "csc_timer_reset", "csc_timer_count", "csc_timer_read", "csc_sparvar_json_write", "csc_format_double", "csc_generate_signals",

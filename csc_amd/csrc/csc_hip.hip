@@ -119,8 +119,8 @@ struct LevelArgs {
     const float* lr_u32;      // low-rank screen (CSC_FLAG_LOWRANK): the basis as one fp32 bank tile | nullptr
     const _Float16* lr_v16;   //   basis coefficients of the bank's columns, fp16 B fragments [16-column block][k-step][lane][8]
     const float* lr_slack;    //   per bank column: what the low-rank product can miss of a correlation, in units of ||r||
-    const uint32_t* simunits; //   [K][su_w] bit u of row k: unit u holds an atom similar to atom k at some shift (CSC_FLAG_SIMUNITS) | nullptr
-    int su_w;                 //   words per row of simunits
+    const uint32_t* simatoms; //   [K][sa_w] bit k' of row k: atom k' is similar to atom k at some shift (CSC_FLAG_SIMATOMS) | nullptr
+    int sa_w;                 //   words per row of simatoms
     int sibling;          // screen16_kernel / mmp_level_tiled16_kernel: the one child (sibling) of each node this launch selects
     int picks_only;       // level 0 ahead of the chain kernel: write the children's (pos, atom) and <atom, signal> only
     int from_root;        // chain kernel: build the level-1 node from the signal and the root level's pick
@@ -3343,50 +3343,19 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
         const float toacc = 64.f * split_scale(am2);
         const float e1 = (9.765625e-4f + 6.103515625e-05f + 1e-6f) * am + 2.98023223876953125e-08f * sqrtf((float)L) * (1.f + am);
         const float band = 2.f * ((EPS3_ACC + 9.5367431640625e-07f) * am + 1.862645149230957e-09f * sqrtf((float)L) * (1.f + am));
-        // A later sibling of a bank with the unit summary of its similarity table (csc_bank_simunits): the residual is the
-        // first sibling's, whose launch left its table in this sibling's row as well, with a lower bound per unit behind
-        // it.  A unit that holds no atom similar to an earlier pick has no suppressed entry: both of its bounds stand.
-        // The others are multiplied (with the suppression), and the node's lower bound is the best of the units that stand.
-        const bool later = t > 0 && a.simunits;
-        unsigned* lbkey = reinterpret_cast<unsigned*>(red);                      // (red is free behind the barrier above)
-        if (later) {
-            if (tid == 0) *lbkey = fkey(-INFINITY);
-            __syncthreads();
-            float m = -INFINITY;
-            for (int u = tid; u < nunits; u += WG) {
-                unsigned hit = 0;
-                for (int q = 0; q < t; ++q)
-                    hit |= (a.simunits[(size_t)spick[CSC_MAX_CONNECTIONS + q] * a.su_w + (u >> 5)] >> (u & 31)) & 1u;
-                nd[u] = (unsigned char)hit;
-                if (!hit) m = fmaxf(m, tab[nunits + 1 + u]);
-            }
-            m = wave_max(m);
-            if (lane == 63) atomicMax(lbkey, fkey(m));
-            __syncthreads();
-        }
-        const float lb = later ? fkey_inv(*lbkey) : tab[nunits];
+        const float lb = tab[nunits];
         for (int u = tid; u < nunits; u += WG) {
             const float ub = tab[u];
 #ifdef CSC_LR_CHECK
             const bool skip = false;
 #else
-            const bool skip = !(later && nd[u]) &&
-                              ub + (e1 + 0.5f * band) * toacc < lb - 2.5f * band * toacc;     // (false on NaN: multiplied)
-#endif
-#ifdef CSC_LR_CHECK
-            if (later && nd[u]) key[u] = fkey(INFINITY);                         // (marks the unit for the check below)
+            const bool skip = ub + (e1 + 0.5f * band) * toacc < lb - 2.5f * band * toacc;     // (false on NaN: multiplied)
 #endif
             nd[u] = skip ? 0 : 1;
             if (skip) key[u] = fkey(ub);
         }
         need = nd;
         __syncthreads();
-#ifdef CSC_LR_CHECK
-        if (tid == 0) *lbkey = fkey(lb);
-        unsigned char* flagged = nd + ((nunits + 15) & ~15);
-        for (int u = tid; u < nunits; u += WG) { flagged[u] = key[u] == fkey(INFINITY); key[u] = fkey(-INFINITY); }
-        __syncthreads();
-#endif
     }
     if (rem) screen_blocks16<true>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring, t, spick, need);
     else screen_blocks16<false>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring, t, spick, need);
@@ -3399,11 +3368,10 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
         const float e1 = (9.765625e-4f + 6.103515625e-05f + 1e-6f) * am + 2.98023223876953125e-08f * sqrtf((float)L) * (1.f + am);
         float mx = -INFINITY;
         for (int u = 0; u < nunits; ++u) mx = fmaxf(mx, fkey_inv(key[u]));
-        const unsigned char* flagged = reinterpret_cast<unsigned char*>(spick + 2 * CSC_MAX_CONNECTIONS) + ((nunits + 15) & ~15);
-        const float lbc = fkey_inv(*reinterpret_cast<unsigned*>(red));
+        const float lbc = tab[nunits];
         for (int u = tid; u < nunits; u += WG) {
             const float got = fkey_inv(key[u]), ub = tab[u];
-            if (!flagged[u] && got > ub + 2.f * e1 * toacc) printf("LRCHK ub: s %d j %d d %d t %d unit %d single %g bound %g (e1 %g)\n", (int)s, j, d, t, u, got, ub, e1 * toacc);
+            if (got > ub + 2.f * e1 * toacc) printf("LRCHK ub: s %d j %d d %d t %d unit %d single %g bound %g (e1 %g)\n", (int)s, j, d, t, u, got, ub, e1 * toacc);
         }
         if (tid == 0 && mx < lbc - e1 * toacc) printf("LRCHK lb: s %d j %d d %d t %d max %g lb %g\n", (int)s, j, d, t, mx, lbc);
     }
@@ -3493,32 +3461,21 @@ __global__ __launch_bounds__(64) void lr_slack_kernel(const double* __restrict__
     }
 }
 
-// Unit summary of a similarity table for this bank: bit u of row k <=> unit u (column group g of bank tile: u = NG tile + g,
-// 48 columns) holds an atom whose similarity row against atom k has a bit set at any shift.  One workgroup per (k, tile).
-__global__ __launch_bounds__(WG) void bank_simunits_kernel(const uint32_t* __restrict__ sim_bits, int W, int K,
-                                                           const int32_t* __restrict__ meta, int su_w,
+// Atom summary of a similarity table: bit k' of row k <=> the similarity row (k, k') has a bit set at any shift.
+// One thread per (k, k'), one word per half wave.
+__global__ __launch_bounds__(WG) void bank_simatoms_kernel(const uint32_t* __restrict__ sim_bits, int W, int K, int sa_w,
                                                            uint32_t* __restrict__ out) {
-    __shared__ int anyu[NG];
-    const int k = blockIdx.x, tile = blockIdx.y, c = threadIdx.x;
-    if (c < NG) anyu[c] = 0;
-    __syncthreads();
-    if (c < CSC_TILE_COLS) {
-        const int atom = meta[(size_t)tile * META_INTS + c];
-        if (atom >= 0) {
-            const uint32_t* row = sim_bits + ((size_t)k * K + atom) * W;
-            uint32_t any = 0;
-            for (int w = 0; w < W; ++w) any |= row[w];
-            if (any) anyu[c / (CSC_TILE_COLS / NG)] = 1;
-        }
+    const int k = blockIdx.y, kp = blockIdx.x * WG + threadIdx.x;
+    uint32_t any = 0;
+    if (kp < K) {
+        const uint32_t* row = sim_bits + ((size_t)k * K + kp) * W;
+        for (int w = 0; w < W; ++w) any |= row[w];
     }
-    __syncthreads();
-    if (c < NG && anyu[c]) {
-        const int u = NG * tile + c;
-        atomicOr(&out[(size_t)k * su_w + (u >> 5)], 1u << (u & 31));
-    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(any != 0);
+    if ((threadIdx.x & 31) == 0 && (kp >> 5) < sa_w) out[(size_t)k * sa_w + (kp >> 5)] = (uint32_t)(m >> (threadIdx.x & 32));
 }
 
-// (SUPP: a later sibling's launch, for callers without the unit summary of their similarity table.  Its similarity-row
+// (SUPP: a later sibling's launch, for callers without the atom summary of their similarity table.  Its similarity-row
 // loads sit behind a per-lane branch, and a loop with such a branch in it waits for every load in flight at each turn; a
 // kernel of its own, so that the first sibling's loop keeps its registers and waits by count)
 template <bool SUPP>
@@ -3533,15 +3490,14 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
     const int nunits = ntile * NG;                                    // (one row block: the host checks P <= 272)
     const int R32 = 272 + nslab * SLAB + 8;
     // LDS: red [4] doubles | r32 [R32] floats | slab [2][SLABF] floats, later T16 [272][LR_TS] halves | masks [nslab] |
-    // key [nunits + 1] (upper bounds, the node's lower bound) | lkey [nunits] (lower bounds) | spick [2][8]
+    // key [nunits + 1] (upper bounds, the node's lower bound) | spick [2][8]
     double* red = lds_raw;
     float* r32 = reinterpret_cast<float*>(red + 4);
     float* slab = r32 + ((R32 + 3) & ~3);
     _Float16* t16 = reinterpret_cast<_Float16*>(slab);
     uint32_t* masks = reinterpret_cast<uint32_t*>(slab + LR_AREA_F);
     unsigned* key = masks + MAX_SLABS;
-    unsigned* lkey = key + nunits + 1;
-    int* spick = reinterpret_cast<int*>(lkey + nunits);
+    int* spick = reinterpret_cast<int*>(key + nunits + 1);
     const int Fd = a.ts.F[d];
     size_t s;
     int j;
@@ -3559,7 +3515,7 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
     for (int i = tid; i < N; i += WG) { const double x = rin[i]; v = fma(x, x, v); }
     v = wave_sum(v);
     if (lane == 63) red[wave] = v;
-    for (int u = tid; u <= 2 * nunits; u += WG) key[u] = fkey(-INFINITY);        // (key and lkey)
+    for (int u = tid; u <= nunits; u += WG) key[u] = fkey(-INFINITY);
     if (tid < MAX_SLABS) masks[tid] = tid < nslab ? (((1u << (LR_R / 16)) - 1u) << (NT - LR_R / 16)) : 0u;
     __syncthreads();
     const double rnorm2 = red[0] + red[1] + red[2] + red[3];
@@ -3670,10 +3626,22 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
             };
             float lo = lane_max(), hi;
             hi = lo;
-            if (SUPP && colok) {
-                // a later sibling: entries similar to an earlier pick take the value 0 (as in screen_blocks16)
+            bool touched = SUPP && colok;
+            int atom = 0;
+            if (SUPP) {
+                // with the atom summary of the similarity table: only columns similar to an earlier pick at some shift
+                // have rows to look up, and most blocks hold none
                 const int tile = b / NT, blk = b - tile * NT;
-                const int atom = a.meta[(size_t)tile * META_INTS + 16 * blk + lr];
+                atom = max(a.meta[(size_t)tile * META_INTS + 16 * blk + lr], 0);
+                if (a.simatoms) {
+                    unsigned hit = 0;
+                    for (int q = 0; q < t; ++q)
+                        hit |= (a.simatoms[(size_t)spick[CSC_MAX_CONNECTIONS + q] * a.sa_w + (atom >> 5)] >> (atom & 31)) & 1u;
+                    touched = touched && hit;
+                }
+            }
+            if (SUPP && touched) {
+                // a later sibling: entries similar to an earlier pick take the value 0 (as in screen_blocks16)
                 const int Wd = a.W;
                 bool any = false;
                 for (int q = 0; q < t; ++q) {
@@ -3700,53 +3668,44 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
             ubl = fmaxf(ubl, colok ? hi + slk : -INFINITY);
             lbl = fmaxf(lbl, colok ? lo - slk : -INFINITY);
         };
-        auto unit_done = [&](int u, float ubl, float lbl) __attribute__((always_inline)) {
-            // bounds of the unit (this half of its rows).  A NaN gives +inf / -inf.
-            float ub = wave_max(ubl) - e1 * toacc, lb = wave_max(lbl);
+        auto unit_done = [&](int u, float ubl) __attribute__((always_inline)) {
+            // upper bound of the unit (this half of its rows).  A NaN gives +inf.
+            float ub = wave_max(ubl) - e1 * toacc;
             if (!(ub == ub)) ub = INFINITY;
-            if (!(lb == lb)) lb = -INFINITY;
-            if (lane == 63) { atomicMax(&key[u], fkey(ub)); atomicMax(&lkey[u], fkey(lb)); }
-            lbmax = fmaxf(lbmax, lb);
+            if (lane == 63) atomicMax(&key[u], fkey(ub));
         };
         const int ufirst = wave >> 1;
         load_b(B0, S0, 3 * ufirst);
         load_b(B1, S1, 3 * ufirst + 1);
         for (int u = ufirst; u < nunits; u += 4) {                     // two units a turn: the buffers come round after six blocks
-            float ubl = -INFINITY, lbl = -INFINITY;
-            block(B0, S0, 3 * u, ubl, lbl);
+            float ubl = -INFINITY;
+            block(B0, S0, 3 * u, ubl, lbmax);
             load_b(B0, S0, 3 * u + 2);
-            block(B1, S1, 3 * u + 1, ubl, lbl);
+            block(B1, S1, 3 * u + 1, ubl, lbmax);
             load_b(B1, S1, 3 * u + 6);
-            block(B0, S0, 3 * u + 2, ubl, lbl);
+            block(B0, S0, 3 * u + 2, ubl, lbmax);
             load_b(B0, S0, 3 * u + 7);
-            unit_done(u, ubl, lbl);
+            unit_done(u, ubl);
             if (u + 2 < nunits) {
-                ubl = -INFINITY; lbl = -INFINITY;
-                block(B1, S1, 3 * u + 6, ubl, lbl);
+                ubl = -INFINITY;
+                block(B1, S1, 3 * u + 6, ubl, lbmax);
                 load_b(B1, S1, 3 * u + 8);
-                block(B0, S0, 3 * u + 7, ubl, lbl);
+                block(B0, S0, 3 * u + 7, ubl, lbmax);
                 load_b(B0, S0, 3 * u + 12);
-                block(B1, S1, 3 * u + 8, ubl, lbl);
+                block(B1, S1, 3 * u + 8, ubl, lbmax);
                 load_b(B1, S1, 3 * u + 13);
-                unit_done(u + 2, ubl, lbl);
+                unit_done(u + 2, ubl);
             }
         }
     };
     if (wave & 1) sweep(std::integral_constant<int, 1>{}); else sweep(std::integral_constant<int, 0>{});
-    if (lane == 63) atomicMax(&key[nunits], fkey(lbmax));              // (lane 63 holds the wave's maxima)
+    if (!(lbmax == lbmax)) lbmax = -INFINITY;
+    lbmax = wave_max(lbmax);
+    if (lane == 63) atomicMax(&key[nunits], fkey(lbmax));
     LR_STAMP(30);
     __syncthreads();
-    // the table: upper bound per unit | the node's lower bound | lower bound per unit.  With the unit summary of the
-    // similarity table the later siblings have no launch of this kernel: their rows take a copy (on the last level
-    // every sibling reads the one row there is)
-    int ncopy = 1;
-    if (a.simunits && t == 0 && d + 1 < a.Kmax)
-        for (int r = 1; r < a.connections; ++r)
-            if ((long long)j + (long long)r * a.ts.pw[d] < a.ts.F[d + 1]) ncopy = r + 1; else break;
-    for (int r = 0; r < ncopy; ++r) {
-        float* tab = screen_table(a, s, j, d, t + r);
-        for (int u = tid; u <= 2 * nunits; u += WG) tab[u] = fkey_inv(key[u]);
-    }
+    float* tab = screen_table(a, s, j, d, t);
+    for (int u = tid; u <= nunits; u += WG) tab[u] = fkey_inv(key[u]);
 }
 
 __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArgs a) {
@@ -4319,10 +4278,10 @@ static size_t bank_lr_elems(int K, int L) {
     if (K <= CSC_TILE_COLS) return 0;
     return (size_t)n_slabs(L) * SLABF + (size_t)n_tiles(K) * NT * (LR_R / 32) * 256 + (size_t)n_tiles(K) * CSC_TILE_COLS;
 }
-// behind it: the unit summary of a similarity table (csc_bank_simunits): K rows of su_words(K) words
-static int su_words(int K) { return (n_tiles(K) * NG + 31) / 32; }
-static size_t bank_su_elems(int K) { return K <= CSC_TILE_COLS ? 0 : (size_t)K * su_words(K); }
-static uint32_t* bank_simunits(const float* d_bank32t, int K, int L) {
+// behind it: the atom summary of a similarity table (csc_bank_simatoms): K rows of sa_words(K) words
+static int sa_words(int K) { return (K + 31) / 32; }
+static size_t bank_sa_elems(int K) { return K <= CSC_TILE_COLS ? 0 : (size_t)K * sa_words(K); }
+static uint32_t* bank_simatoms(const float* d_bank32t, int K, int L) {
     return reinterpret_cast<uint32_t*>(const_cast<float*>(d_bank32t) + bank_base_elems(K, L) + bank_lr_elems(K, L));
 }
 static float* bank_lr_u32(const float* d_bank32t, int K, int L) { return const_cast<float*>(d_bank32t) + bank_base_elems(K, L); }
@@ -4391,23 +4350,20 @@ const char* csc_last_error(void) { return g_err; }
 
 size_t csc_bank32_elems(int K, int L) {
     if (K <= 0 || L <= 0) return 0;
-    return bank_base_elems(K, L) + bank_lr_elems(K, L) + bank_su_elems(K);
+    return bank_base_elems(K, L) + bank_lr_elems(K, L) + bank_sa_elems(K);
 }
 
 int csc_lowrank_rank(void) { return LR_R; }
 
-int csc_bank_simunits(float* d_bank32t, int K, int L, const uint32_t* d_sim_bits, int W, void* stream) {
-    if (!d_bank32t || !d_sim_bits || K <= 0 || L <= 0 || W <= 0) FAIL(-1, "csc_bank_simunits: bad arguments");
-    if (K <= CSC_TILE_COLS) FAIL(-13, "csc_bank_simunits: dictionaries of one bank tile (K <= %d) have no low-rank screen", CSC_TILE_COLS);
-    if (n_tiles(K) > 65535) FAIL(-11, "csc_bank_simunits: dictionary too large (%d atoms)", K);
+int csc_bank_simatoms(float* d_bank32t, int K, int L, const uint32_t* d_sim_bits, int W, void* stream) {
+    if (!d_bank32t || !d_sim_bits || K <= 0 || L <= 0 || W <= 0) FAIL(-1, "csc_bank_simatoms: bad arguments");
+    if (K <= CSC_TILE_COLS) FAIL(-13, "csc_bank_simatoms: dictionaries of one bank tile (K <= %d) have no low-rank screen", CSC_TILE_COLS);
+    if (K > 65535) FAIL(-11, "csc_bank_simatoms: dictionary too large (%d atoms)", K);
     hipStream_t st = (hipStream_t)stream;
     clear_stale_error();
-    uint32_t* out = bank_simunits(d_bank32t, K, L);
-    hipError_t e = hipMemsetAsync(out, 0, bank_su_elems(K) * 4, st);
-    if (e != hipSuccess) FAIL((int)e, "csc_bank_simunits: hipMemsetAsync: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(bank_simunits_kernel, dim3((unsigned)K, (unsigned)n_tiles(K)), dim3(WG), 0, st, d_sim_bits, W, K,
-                       bank_meta(d_bank32t, K, L), su_words(K), out);
-    return launch_status("bank_simunits_kernel");
+    hipLaunchKernelGGL(bank_simatoms_kernel, dim3((unsigned)((K + WG - 1) / WG), (unsigned)K), dim3(WG), 0, st, d_sim_bits, W, K,
+                       sa_words(K), bank_simatoms(d_bank32t, K, L));
+    return launch_status("bank_simatoms_kernel");
 }
 
 int csc_bank_lowrank(float* d_bank32t, const double* d_bank64, int K, int L, const double* d_basis, int rank, void* stream) {
@@ -4616,18 +4572,18 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
     const size_t units16 = (size_t)n_tiles(K) * nrb16 * NG;
     const size_t lds_screen = 4 * 8 + (size_t)R16_COPIES * r16t_stride(P, Lp) * 2 + (size_t)TRING * TG_BLK * 2 + units16 * 4 +
                               (((size_t)n_tiles(K) * NT * 2 + 15) & ~(size_t)15) + 2 * CSC_MAX_CONNECTIONS * 4 +
-                              2 * ((units16 + 15) & ~(size_t)15);
-    const size_t lds_lr = 32 + (size_t)ceil4(272 + Lp + 8) * 4 + (size_t)LR_AREA_F * 4 + MAX_SLABS * 4 + (2 * units16 + 1) * 4 +
+                              ((units16 + 15) & ~(size_t)15);
+    const size_t lds_lr = 32 + (size_t)ceil4(272 + Lp + 8) * 4 + (size_t)LR_AREA_F * 4 + MAX_SLABS * 4 + (units16 + 1) * 4 +
                           2 * CSC_MAX_CONNECTIONS * 4;
     const bool tiled16 = tiled && !(flags & CSC_FLAG_FP32_ONLY) && node_flags && mode == 0 && L <= 682 &&
                          lds16 <= 150 * 1024 && (long long)n_tiles(K) * nrb * NG <= MAX_UNITS16 && n_tiles(K) * NT <= 2 * MAX_UNITS16 &&
-                         lds_screen <= 100 * 1024 && (2 * units16 + 1) * 4 <= (size_t)(N + TRI(max_sparsity) + max_sparsity) * 8;
+                         lds_screen <= 100 * 1024 && (units16 + 1) * 4 <= (size_t)(N + TRI(max_sparsity) + max_sparsity) * 8;
     clear_stale_error();
     // the low-rank screen in front (the caller vouches for an installed section: csc_bank_lowrank): one row block only
     const bool lowrank = tiled16 && (flags & CSC_FLAG_LOWRANK) && P >= CSC_TILE_ROWS && P <= 272 && lds_lr <= 80 * 1024;
-    // ... and the unit summary of d_sim_bits (csc_bank_simunits, vouched for likewise): the later siblings of a node take
-    // their bounds from the first sibling's low-rank product
-    const bool simunits = lowrank && (flags & CSC_FLAG_SIMUNITS) && d_sim_bits;
+    // ... and the atom summary of d_sim_bits (csc_bank_simatoms, vouched for likewise): the later siblings' low-rank product
+    // looks up similarity rows only for the columns the summary names
+    const bool simatoms = lowrank && (flags & CSC_FLAG_SIMATOMS) && d_sim_bits;
     if (tiled16) {
         hipFuncSetAttribute((const void*)mmp_level_tiled16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
         hipFuncSetAttribute((const void*)screen16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_screen);
@@ -4664,7 +4620,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         const int span = timer_begin(st, d);
         a.flags = nullptr; a.S = S; a.signals = d_signals; a.ws[0] = ws[0]; a.ws[1] = ws[1];
         a.picks_only = 0; a.from_root = 0; a.sibling = -1;
-        a.lr_u32 = nullptr; a.lr_v16 = nullptr; a.lr_slack = nullptr; a.simunits = nullptr; a.su_w = 0;
+        a.lr_u32 = nullptr; a.lr_v16 = nullptr; a.lr_slack = nullptr; a.simatoms = nullptr; a.sa_w = 0;
         // level 0 in front of the chain kernel (every node of level 1 has one child): it only has to pick -- the chain
         // kernel builds a pick's node from the signal, so no child residual crosses HBM between the two launches
         const bool root_picks = lean && mode == 0 && d == 0 && max_sparsity > 1 && connections > 1 && ts.pw[1] >= ts.F[2];
@@ -4681,12 +4637,13 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
             a.lr_u32 = lowrank ? bank_lr_u32(d_bank32t, K, L) : nullptr;
             a.lr_v16 = lowrank ? bank_lr_v16(d_bank32t, K, L) : nullptr;
             a.lr_slack = lowrank ? bank_lr_slack(d_bank32t, K, L) : nullptr;
-            a.simunits = simunits ? bank_simunits(d_bank32t, K, L) : nullptr;
-            a.su_w = su_words(K);
+            a.simatoms = simatoms ? bank_simatoms(d_bank32t, K, L) : nullptr;
+            a.sa_w = sa_words(K);
             for (int t = 0; t < nsib; ++t) {
                 a.sibling = t;
                 if (lowrank && t == 0) hipLaunchKernelGGL(screen_lr_kernel<false>, dim3((unsigned)grid), dim3(WG), lds_lr, st, a);
-                else if (lowrank && !simunits) hipLaunchKernelGGL(screen_lr_kernel<true>, dim3((unsigned)grid), dim3(WG), lds_lr, st, a);
+                else if (lowrank) hipLaunchKernelGGL(screen_lr_kernel<true>, dim3((unsigned)grid), dim3(WG), lds_lr, st, a);
+
                 hipLaunchKernelGGL(screen16_kernel, dim3((unsigned)grid), dim3(WG), lds_screen, st, a);
                 hipLaunchKernelGGL(mmp_level_tiled16_kernel, dim3((unsigned)grid), dim3(WG), lds16, st, a);
             }

@@ -156,8 +156,8 @@ class DeviceBank:
                                                          _ptr(self._basis), r, _stream(self.device)), "csc_bank_lowrank")
                     self.lowrank = True                              # set to False to screen in full (same results)
         self._sim = {}
-        self._simunits_for = None        # the similarity table whose unit summary sits in the bank image (csc_bank_simunits)
-        self.simunits = True             # set to False to repeat the low-rank product per sibling (same results)
+        self._simatoms_for = None        # the similarity table whose atom summary sits in the bank image (csc_bank_simatoms)
+        self.simatoms = True             # set to False to look up every column's similarity rows in the later siblings' screen (same results)
         # correlations on the fp16 matrix cores as a filter in front of the float64 re-score (same results);
         # set to True to correlate in fp32 only (CSC_FLAG_FP32_ONLY)
         self.fp32_only = False
@@ -344,12 +344,12 @@ class DeviceBank:
                 }
             flags = ((1 if self.fp32_only else 0) | (0 if self.lean else 2) | 4        # 4 = CSC_FLAG_RECORDS_AOS
                      | (8 if self.lowrank else 0))                                 # 8 = CSC_FLAG_LOWRANK
-            if self.lowrank and self.simunits and sim is not None:
-                # the unit summary of THIS table in the bank image (once per table; 16 = CSC_FLAG_SIMUNITS)
-                if self._simunits_for is not sim:
-                    _lib.check(self.lib.csc_bank_simunits(_ptr(self.bank32t), self.K, self.L, _ptr(sim),
-                                                          self.lib.csc_sim_words(N, self.L), _stream(dev)), "csc_bank_simunits")
-                    self._simunits_for = sim
+            if self.lowrank and self.simatoms and sim is not None:
+                # the atom summary of THIS table in the bank image (once per table; 16 = CSC_FLAG_SIMATOMS)
+                if self._simatoms_for is not sim:
+                    _lib.check(self.lib.csc_bank_simatoms(_ptr(self.bank32t), self.K, self.L, _ptr(sim),
+                                                          self.lib.csc_sim_words(N, self.L), _stream(dev)), "csc_bank_simatoms")
+                    self._simatoms_for = sim
                 flags |= 16
             tail = (_ptr(out["node_pos"]), _ptr(out["node_atom"]), _ptr(out["node_mse"]), _ptr(out["node_coef"]),
                     _ptr(out["rec_buf"]), None, None, _ptr(out["stats"]), _stream(dev))

@@ -35,7 +35,7 @@ extern "C" {
 #define CSC_FLAG_NO_LEAN 2     /* keep single-child levels on the register-resident kernel      */
 #define CSC_FLAG_RECORDS_AOS 4 /* per-sparsity records as one contiguous record per signal      */
 #define CSC_FLAG_LOWRANK 8     /* the bank image holds a low-rank section (csc_bank_lowrank)     */
-#define CSC_FLAG_SIMUNITS 16   /* ... and the unit summary of d_sim_bits (csc_bank_simunits)     */
+#define CSC_FLAG_SIMATOMS 16   /* ... and the atom summary of d_sim_bits (csc_bank_simatoms)     */
 #define CSC_STATIC_SCRATCH_BYTES (64u << 20)   /* static device scratch of csc_mmpdf_batch_static      */
 
 int csc_abi_version(void);
@@ -65,15 +65,15 @@ int csc_bank_pack(const double* d_bank64, int K, int L, float* d_bank32t, void* 
 int csc_lowrank_rank(void);
 int csc_bank_lowrank(float* d_bank32t, const double* d_bank64, int K, int L, const double* d_basis, int rank, void* stream);
 
-/* Unit summary of a similarity table for the low-rank screen (K > 144; no counterpart in the reference, which masks the
+/* Atom summary of a similarity table for the low-rank screen (K > 144; no counterpart in the reference, which masks the
  * correlations of every sibling in full, src/csc/mmp.py:196-201).  d_sim_bits / W: a table of csc_similarity_table[_packed]
- * for this bank and its row length csc_sim_words(N, L).  Records in the packed bank, per atom k and per 48-column unit
- * of the bank image, whether the unit holds an atom with any bit set in k's similarity rows.  csc_mmpdf_batch with
- * CSC_FLAG_LOWRANK | CSC_FLAG_SIMUNITS and THAT table then bounds a node's second and later children from the first
- * child's low-rank product (the residual is the same; only units that hold an atom similar to an earlier pick are
- * multiplied again) instead of repeating the product under the suppression; results are identical with or without it.
- * Call it again whenever the table passed to csc_mmpdf_batch changes (another threshold or signal length). */
-int csc_bank_simunits(float* d_bank32t, int K, int L, const uint32_t* d_sim_bits, int W, void* stream);
+ * for this bank and its row length csc_sim_words(N, L).  Records in the packed bank, per pair of atoms, whether their
+ * similarity row has a bit set at any shift (K x ceil(K / 32) words).  With CSC_FLAG_LOWRANK | CSC_FLAG_SIMATOMS and THAT
+ * table, the low-rank screen of a node's second and later children reads similarity rows only for the columns the
+ * summary names (most 16-column blocks hold none) instead of 6 words per column and earlier pick; results are identical
+ * with or without it.  Call it again whenever the table passed to csc_mmpdf_batch changes (another threshold or signal
+ * length). */
+int csc_bank_simatoms(float* d_bank32t, int K, int L, const uint32_t* d_sim_bits, int W, void* stream);
 
 /* Atom-vs-dictionary similarity table.  Replaces, for every node, the
  * computeCorrelations(atom_signal)/||atom_signal|| <= thr mask of src/csc/mmp.py:92-93,196-201:

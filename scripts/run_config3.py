@@ -1,5 +1,5 @@
 """BASELINE.json config 3 alone (9570-atom dictionary, c3/B3/K5), for profiling:
-    python3 scripts/run_config3.py [signals] [reps] [--fp32] [--no-lowrank] [--no-simunits]
+    python3 scripts/run_config3.py [signals] [reps] [--fp32] [--no-lowrank] [--no-simatoms]
 prints one JSON line with the throughput; under rocprofv3 the kernels of the timed calls are what is traced."""
 import json
 import sys
@@ -21,8 +21,8 @@ bank = large.device_bank()
 bank.fp32_only = "--fp32" in sys.argv
 if "--no-lowrank" in sys.argv:
     bank.lowrank = False
-if "--no-simunits" in sys.argv:
-    bank.simunits = False
+if "--no-simatoms" in sys.argv:
+    bank.simatoms = False
 d = torch.from_numpy(sigs).cuda()
 out = bank.mmpdf_launch(d, 5, 3, 3, 0.8, want_coef=False)
 torch.cuda.synchronize()
