@@ -116,7 +116,7 @@ struct LevelArgs {
     int S;                // signals
     const double* signals;    // [S][N]            } the chain kernels walk several levels: level e reads
     double* ws[2];            // [S][F][NS] each   } signals (e == 0) or ws[e & 1] and writes ws[(e + 1) & 1]
-    const float* lr_u32;      // low-rank screen (CSC_FLAG_LOWRANK): the basis as one fp32 bank tile | nullptr
+    const _Float16* lr_u16;   // low-rank screen (CSC_FLAG_LOWRANK): the basis x 64 as fp16 B fragments [hi | lo][k-step][16-column block][lane][8] | nullptr
     const _Float16* lr_v16;   //   basis coefficients of the bank's columns, fp16 B fragments [16-column block][k-step][lane][8]
     const float* lr_slack;    //   per bank column: what the low-rank product can miss of a correlation, in units of ||r||
     const uint32_t* simatoms; //   [K][sa_w] bit k' of row k: atom k' is similar to atom k at some shift (CSC_FLAG_SIMATOMS) | nullptr
@@ -3333,7 +3333,7 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
     const _Float16* hi_all = reinterpret_cast<const _Float16*>(a.bank16);
     float* tab = screen_table(a, s, j, d, t);
     const unsigned char* need = nullptr;
-    if (a.lr_u32) {
+    if (a.lr_u16) {
         // behind screen_lr_kernel: its table holds, per unit, an upper bound (less e1) of what the unit can hold and, behind
         // the units, a lower bound LB of the node's maximum.  A unit whose bound + e1 + band / 2 (the most the three-product
         // sweep can find there) stays 2 bands below LB - band / 2 (the least its running maximum ends at) is never visited
@@ -3361,7 +3361,7 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
     else screen_blocks16<false>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring, t, spick, need);
     __syncthreads();
 #ifdef CSC_LR_CHECK
-    if (a.lr_u32) {
+    if (a.lr_u16) {
         // development aid: every unit multiplied; its single-term maximum against the low-rank bounds
         const float am = sqrtf(am2);
         const float toacc = 64.f * split_scale(am2);
@@ -3388,27 +3388,30 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
 //     <r_window, a_k> = (r_window U) V16_k + <r_window, res_k>,     |<r_window, res_k>| <= ||r|| ||res_k||
 // so C~ = T V16 with T = R U -- the Hankel product against 64 columns instead of K, then a GEMM of depth 64: 34 MFMAs per
 // 16-column block where the single-term screen issues ~190 -- bounds every correlation of a column to within
-//     slack_k = ||res_k|| + (2^-11 + sqrt(64) (L + 8) 2^-23 + 64 2^-24 + 2^-20) ||V16_k||        (units of ||r||)
-// (T rounded to fp16; T itself from the fp32 matrix cores: both operands rounded to fp32, L accumulations per entry, 64
-// entries per row; the fp32 accumulation of the second product; fp16 subnormals of T).  Any basis is valid -- the slack is
+//     slack_k = ||res_k|| + (2^-11 + sqrt(64) ((L + 40) 2^-24 + 2^-20 + ..) + 64 2^-24 + 2^-20) ||V16_k||   (units of ||r||)
+// (T rounded to fp16; T itself from the fp16 matrix cores with two-term operands: the accumulation of L products per
+// entry, the operand splits, 64 entries per row; the fp32 accumulation of the second product; fp16 subnormals of T:
+// lr_slack_kernel).  Any basis is valid -- the slack is
 // computed from the V16 actually used -- as long as its vectors are orthonormal (||T_p|| <= ||r_window||).
 // screen_lr_kernel leaves per unit  max(C~ + slack) - e1  in the screen table (mmp_level_tiled16_kernel adds e1 back) and,
 // behind the units, a LOWER bound of the node's maximum: max(C~ - slack).  screen16_kernel, launched behind, then takes
 // the single-term product only of the units whose low-rank bound can still reach that maximum (a tenth of them).
 #define LR_R 64                        // rank of the screen
-#define LR_TS (LR_R + 8)               // row stride of T in LDS (halves): 144 B, 16-byte aligned rows
-#define LR_AREA_F ((2 * SLABF > 272 * LR_TS / 2) ? 2 * SLABF : 272 * LR_TS / 2)   // floats: the slab buffers, then T16
+#define LR_PLANE_H (272 * 32)          // halves of one plane of T16 in LDS: [row][32 columns] (k-step of the second product)
 
-__global__ void lr_pack_u_kernel(const double* __restrict__ basis, int L, int nslab, float* __restrict__ u32) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)nslab * SLABF) return;
-    const int col16 = (int)(i & 15), row = (int)((i >> 4) & (SLAB - 1));
-    size_t t = i / BLKF;
-    const int ni = (int)(t % NT);
-    const int slab = (int)(t / NT);
-    const int c = 16 * ni + col16 - (CSC_TILE_COLS - LR_R);           // the basis sits in the tile's LAST columns
-    const int l = slab * SLAB + row;
-    u32[i] = (c >= 0 && l < L) ? (float)basis[(size_t)c * L + l] : 0.f;
+// U16 [hi | lo][k-step][16-column block][lane][j] = the two fp16 terms of 64 U[l][i], l = 32 ks + 8 (lane >> 4) + j,
+// i = 16 block + (lane & 15): B fragments of v_mfma_f32_16x16x32_f16 (the scale keeps the lo terms of all but the
+// smallest entries out of the fp16 subnormals, as split_scale does for the bank)
+__global__ void lr_pack_u16_kernel(const double* __restrict__ basis, int L, int nks, _Float16* __restrict__ u16) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)nks * (LR_R / 16) * 512;
+    if (e >= total) return;
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), nb = (int)((e >> 9) % (LR_R / 16)), ks = (int)(e / (512 * (LR_R / 16)));
+    const int l = 32 * ks + 8 * (lane >> 4) + j, i = 16 * nb + (lane & 15);
+    const double x = l < L ? 64.0 * basis[(size_t)i * L + l] : 0.0;
+    const _Float16 h = (_Float16)x;
+    u16[e] = h;
+    u16[total + e] = (_Float16)(x - (double)h);
 }
 // V16[block][ks][lane][j] = fl16(2^sa <U_i, a_k>), i = 32 ks + 8 (lane >> 4) + j, k = atom of column 16 block + (lane & 15)
 __global__ void lr_pack_v_kernel(const double* __restrict__ basis, const double* __restrict__ bank64, int K, int L,
@@ -3456,7 +3459,12 @@ __global__ __launch_bounds__(64) void lr_slack_kernel(const double* __restrict__
     rr = wave_sum(rr);
     vv = wave_sum(vv);
     if (lane == 63) {
-        const double rel = 4.8828125e-04 + 8.0 * (double)(L + 8) * 1.1920928955078125e-07 + 64.0 * 5.9604644775390625e-08 + 9.5367431640625e-07;
+        // T to fp16: 2^-11; T itself: sqrt(64) entries per row, each off by (L + 40) 2^-24 (fp32 accumulation of the
+        // rh uh chain over the padded window, the cross chain and the final sum) + 2^-20 (operand splits, the dropped
+        // product) + 2^-28 sqrt(L + 32) (fp16 subnormals of the lo terms); 64 2^-24: fp32 accumulation of the second
+        // product; 2^-20: fp16 subnormals of T
+        const double relT = (double)(L + 40) * 5.9604644775390625e-08 + 9.5367431640625e-07 + 3.725290298461914e-09 * sqrt((double)(L + 32));
+        const double rel = 4.8828125e-04 + 8.0 * relT + 64.0 * 5.9604644775390625e-08 + 9.5367431640625e-07;
         slack[col] = (float)((sqrt(rr) + rel * sqrt(vv)) * 1.000001 + 1e-30);
     }
 }
@@ -3488,15 +3496,15 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
     const int ntile = (K + CSC_TILE_COLS - 1) / CSC_TILE_COLS;
     const int nslab = (L + SLAB - 1) / SLAB;
     const int nunits = ntile * NG;                                    // (one row block: the host checks P <= 272)
-    const int R32 = 272 + nslab * SLAB + 8;
-    // LDS: red [4] doubles | r32 [R32] floats | slab [2][SLABF] floats, later T16 [272][LR_TS] halves | masks [nslab] |
+    const int CS = r16t_stride(P, nslab * SLAB);                      // halves per shifted copy of the residual window
+    // LDS: red [4] doubles | rh, rl [8][CS] halves each, later plane 1 of T16 | plane 0 of T16 [272][32] halves |
     // key [nunits + 1] (upper bounds, the node's lower bound) | spick [2][8]
     double* red = lds_raw;
-    float* r32 = reinterpret_cast<float*>(red + 4);
-    float* slab = r32 + ((R32 + 3) & ~3);
-    _Float16* t16 = reinterpret_cast<_Float16*>(slab);
-    uint32_t* masks = reinterpret_cast<uint32_t*>(slab + LR_AREA_F);
-    unsigned* key = masks + MAX_SLABS;
+    _Float16* rh = reinterpret_cast<_Float16*>(red + 4);
+    _Float16* rl = rh + R16_COPIES * CS;
+    _Float16* t16p1 = rh;
+    _Float16* t16p0 = rl + R16_COPIES * CS;
+    unsigned* key = reinterpret_cast<unsigned*>(t16p0 + LR_PLANE_H);
     int* spick = reinterpret_cast<int*>(key + nunits + 1);
     const int Fd = a.ts.F[d];
     size_t s;
@@ -3516,13 +3524,21 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
     v = wave_sum(v);
     if (lane == 63) red[wave] = v;
     for (int u = tid; u <= nunits; u += WG) key[u] = fkey(-INFINITY);
-    if (tid < MAX_SLABS) masks[tid] = tid < nslab ? (((1u << (LR_R / 16)) - 1u) << (NT - LR_R / 16)) : 0u;
     __syncthreads();
     const double rnorm2 = red[0] + red[1] + red[2] + red[3];
     const float am2 = *a.amax2, am = sqrtf(am2);
     if (!(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 0.5e-30 && rnorm2 < 2e30)) return;   // (as screen16_kernel)
-    const double sc = 64.0 / sqrt(rnorm2);
-    for (int i = tid; i < R32; i += WG) r32[i] = i < N ? (float)(rin[i] * sc) : 0.f;
+    {
+        // the residual as a two-term fp16 number, scaled to norm 64, in 8 shifted copies each (as mmp_level_tiled16_kernel)
+        const double sc = 64.0 / sqrt(rnorm2);
+        for (int i = tid; i < R16_COPIES * CS; i += WG) {
+            const int c = i / CS, e = i - c * CS + c;
+            const double x = e < N ? rin[e] * sc : 0.0;
+            const _Float16 h = (_Float16)x;
+            rh[i] = h;
+            rl[i] = (_Float16)(x - (double)h);
+        }
+    }
     __syncthreads();
 #ifdef CSC_PHASE_PROF
     unsigned long long lr_t = __builtin_readcyclecounter();
@@ -3531,33 +3547,85 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
 #else
 #define LR_STAMP(i)
 #endif
-    // ---- T = R U on the fp32 matrix cores: rows 0 .. 255 (corr_tile_gemm), 256 .. 271 (corr_rem_gemm) --------------------
+    // ---- T = R U on the fp16 matrix cores, both operands two-term fp16 numbers (the window copies above; the basis
+    // scaled by 64 as B fragments hi | lo in the bank image, straight from L2 a k-step ahead): per k-step and 16 x 16 tile
+    // rh uh into one accumulator, rh ul + rl uh into another (rl ul ~ 2^-22 is dropped) -- the cross terms are 2^-11 of the
+    // product, so the fp32 accumulation error is that of the first chain alone: L 2^-24 instead of 3 L 2^-24.
+    // Wave w: row tiles 4 w .. 4 w + 3 x the basis' four 16-column blocks, and block w of the remainder tile (rows 256 ..);
+    // two passes of two column blocks (72 accumulators); pass p writes plane p of T16 [k-step of the second product][row][32]:
+    // plane 0 beside the window copies, plane 1 over them once every wave has left the product --------------------------
     {
-        // (the remainder rows first: their one accumulator per wave waits in registers while the main product runs;
-        // T16 shares the slab buffers' space and is written when both products are done -- each ends with a barrier)
-        f32x4 acc[MT][NT];
-        corr_rem_gemm(a.lr_u32, masks, nslab, r32 + CSC_TILE_ROWS + lr + lq, slab, acc);
-        f32x4 remv = acc[0][NT - 1];
-        int remni = NT - 1;
+        const int nks = nslab;                                         // k-steps of 32
+        const _Float16* uh = a.lr_u16 + lane * 8;
+        const _Float16* ul = uh + (size_t)nks * (LR_R / 16) * 512;
+        const int c8 = lr & 7;
+        const _Float16* ah0 = rh + c8 * CS + (64 * wave + lr - c8) + 8 * lq;      // (tile i: + 16 i; the remainder tile: below)
+        const _Float16* ahr = rh + c8 * CS + (CSC_TILE_ROWS + lr - c8) + 8 * lq;
+        const int dlo = R16_COPIES * CS;                               // rl - rh
+        auto pass = [&](int p, bool extra, _Float16* plane) __attribute__((always_inline)) {
+            f32x4 hh[9], xx[9];
 #pragma unroll
-        for (int ni = NT - LR_R / 16; ni < NT - 1; ++ni)
-            if ((ni & 3) == wave) { remv = acc[0][ni]; remni = ni; }
-        const bool remmine = (remni & 3) == wave;
-        corr_tile_gemm(a.lr_u32, masks, nslab, r32 + 64 * wave + lr + lq, slab, acc);
+            for (int i = 0; i < 9; ++i) { hh[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; xx[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            const bool odd = wave & 1;                                 // the remainder tile's column block (extra): 2 p + odd
+            // (no second buffer for the B fragments: the lo pair is re-loaded behind its one use, a third of a k-step
+            // early, the hi pair at the end of the k-step -- the other waves of the SIMD cover what latency is left)
+            f16x8 bh[2], bl[2];
+            auto load_u = [&](f16x8 (&B)[2], const _Float16* src, int ks) __attribute__((always_inline)) {
+#ifdef LR_EXP_NOLOADU
+                const int kk = min(ks, 0);
+#else
+                const int kk = min(ks, nks - 1);                       // (past the end: the last k-step again, unused)
+#endif
 #pragma unroll
-        for (int ni = NT - LR_R / 16; ni < NT; ++ni) {
-            const int c = 16 * (ni - (NT - LR_R / 16)) + lr;
+                for (int n = 0; n < 2; ++n)
+                    B[n] = *reinterpret_cast<const f16x8*>(src + ((size_t)kk * (LR_R / 16) + 2 * p + n) * 512);
+            };
+            load_u(bh, uh, 0);
+            load_u(bl, ul, 0);
+            for (int ks = 0; ks < nks; ++ks) {
+                f16x8 Ah[5], Al[5];
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
+                for (int i = 0; i < 4; ++i) Ah[i] = *reinterpret_cast<const f16x8*>(ah0 + 16 * i + 32 * ks);
+                Ah[4] = *reinterpret_cast<const f16x8*>(ahr + 32 * ks);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) xx[2 * i + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[i], bl[n], xx[2 * i + n], 0, 0, 0);
+                if (extra) xx[8] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[4], (odd ? bl[1] : bl[0]), xx[8], 0, 0, 0);
+                load_u(bl, ul, ks + 1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Al[i] = *reinterpret_cast<const f16x8*>(ah0 + dlo + 16 * i + 32 * ks);
+                Al[4] = *reinterpret_cast<const f16x8*>(ahr + dlo + 32 * ks);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) hh[2 * i + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[i], bh[n], hh[2 * i + n], 0, 0, 0);
+                if (extra) hh[8] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[4], (odd ? bh[1] : bh[0]), hh[8], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) xx[2 * i + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[i], bh[n], xx[2 * i + n], 0, 0, 0);
+                if (extra) xx[8] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[4], (odd ? bh[1] : bh[0]), xx[8], 0, 0, 0);
+                load_u(bh, uh, ks + 1);
+            }
+            if (p == 1) __syncthreads();                               // every wave has left the window copies: plane 1 goes there
+            // accumulators (64 x 64 <r window, u> / ||r||) -> T16 = fl16(64 <r window, u> / ||r||)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        plane[(64 * wave + 16 * i + 4 * lq + rg) * 32 + 16 * n + lr] =
+                            (_Float16)((hh[2 * i + n][rg] + xx[2 * i + n][rg]) * 0.015625f);
+            if (extra) {
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg)
-                    t16[(64 * wave + 16 * mi + 4 * lq + rg) * LR_TS + c] = (_Float16)acc[mi][ni][rg];
-        }
-        if (remmine) {
-            const int c = 16 * (remni - (NT - LR_R / 16)) + lr;
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) t16[(CSC_TILE_ROWS + 4 * lq + rg) * LR_TS + c] = (_Float16)remv[rg];
-        }
+                    plane[(CSC_TILE_ROWS + 4 * lq + rg) * 32 + 16 * (wave & 1) + lr] = (_Float16)((hh[8][rg] + xx[8][rg]) * 0.015625f);
+            }
+        };
+        pass(0, wave < 2, t16p0);
+        pass(1, wave >= 2, t16p1);
     }
     __syncthreads();
     LR_STAMP(29);
@@ -3581,7 +3649,7 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
         for (int i = 0; i < NS; ++i)
 #pragma unroll
             for (int ks = 0; ks < LR_R / 32; ++ks)
-                A[i][ks] = *reinterpret_cast<const f16x8*>(t16 + (16 * (9 * HALF + i) + lr) * LR_TS + 32 * ks + 8 * lq);
+                A[i][ks] = *reinterpret_cast<const f16x8*>((ks ? t16p1 : t16p0) + (16 * (9 * HALF + i) + lr) * 32 + 8 * lq);
         // rows past the matrix (the remainder tile: the second half's last) start from -1e30 instead of 0 and stay there:
         // no masks behind the products
         f32x4 initl = {0.f, 0.f, 0.f, 0.f};
@@ -4270,13 +4338,13 @@ static const _Float16* bank_tiles16s(const float* d_bank32t, int K, int L, int l
     return reinterpret_cast<const _Float16*>(end) + (lo ? tile_floats(K, L) : 0);
 }
 // behind the scaled tiles, for dictionaries of more than one bank tile: the low-rank section (csc_bank_lowrank):
-// [basis as one fp32 tile: n_slabs * SLABF floats][V16: n_tiles * 9 * (LR_R / 32) * 512 halves][slack: n_tiles * 144 floats]
+// [basis x 64 as fp16 B fragments, hi | lo: 2 * n_slabs * 4 * 512 halves][V16: n_tiles * 9 * (LR_R / 32) * 512 halves][slack: n_tiles * 144 floats]
 static size_t bank_base_elems(int K, int L) {
     return bank16_offset(K, L) + tile_floats(K, L) / 2 + 16 + 2 * (size_t)(K + (K & 1)) + tile_floats(K, L);
 }
 static size_t bank_lr_elems(int K, int L) {
     if (K <= CSC_TILE_COLS) return 0;
-    return (size_t)n_slabs(L) * SLABF + (size_t)n_tiles(K) * NT * (LR_R / 32) * 256 + (size_t)n_tiles(K) * CSC_TILE_COLS;
+    return (size_t)n_slabs(L) * (LR_R / 16) * 512 + (size_t)n_tiles(K) * NT * (LR_R / 32) * 256 + (size_t)n_tiles(K) * CSC_TILE_COLS;
 }
 // behind it: the atom summary of a similarity table (csc_bank_simatoms): K rows of sa_words(K) words
 static int sa_words(int K) { return (K + 31) / 32; }
@@ -4285,11 +4353,12 @@ static uint32_t* bank_simatoms(const float* d_bank32t, int K, int L) {
     return reinterpret_cast<uint32_t*>(const_cast<float*>(d_bank32t) + bank_base_elems(K, L) + bank_lr_elems(K, L));
 }
 static float* bank_lr_u32(const float* d_bank32t, int K, int L) { return const_cast<float*>(d_bank32t) + bank_base_elems(K, L); }
+static size_t bank_lr_u_floats(int L) { return (size_t)n_slabs(L) * (LR_R / 16) * 512; }   // hi + lo fragments, as floats
 static _Float16* bank_lr_v16(const float* d_bank32t, int K, int L) {
-    return reinterpret_cast<_Float16*>(bank_lr_u32(d_bank32t, K, L) + (size_t)n_slabs(L) * SLABF);
+    return reinterpret_cast<_Float16*>(bank_lr_u32(d_bank32t, K, L) + bank_lr_u_floats(L));
 }
 static float* bank_lr_slack(const float* d_bank32t, int K, int L) {
-    return bank_lr_u32(d_bank32t, K, L) + (size_t)n_slabs(L) * SLABF + (size_t)n_tiles(K) * NT * (LR_R / 32) * 256;
+    return bank_lr_u32(d_bank32t, K, L) + bank_lr_u_floats(L) + (size_t)n_tiles(K) * NT * (LR_R / 32) * 256;
 }
 static const int32_t* bank_meta(const float* d_bank32t, int K, int L) {
     return reinterpret_cast<const int32_t*>(d_bank32t + tile_floats(K, L));
@@ -4374,9 +4443,9 @@ int csc_bank_lowrank(float* d_bank32t, const double* d_bank64, int K, int L, con
     hipStream_t st = (hipStream_t)stream;
     const int nslab = n_slabs(L), ntile = n_tiles(K);
     clear_stale_error();
-    const size_t nu = (size_t)nslab * SLABF;
-    hipLaunchKernelGGL(lr_pack_u_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, d_basis, L, nslab,
-                       bank_lr_u32(d_bank32t, K, L));
+    const size_t nu = (size_t)nslab * (LR_R / 16) * 512;
+    hipLaunchKernelGGL(lr_pack_u16_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, d_basis, L, nslab,
+                       reinterpret_cast<_Float16*>(bank_lr_u32(d_bank32t, K, L)));
     const size_t nv = (size_t)ntile * NT * (LR_R / 32) * 512;
     hipLaunchKernelGGL(lr_pack_v_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, d_basis, d_bank64, K, L,
                        bank_meta(d_bank32t, K, L), bank_amax2(d_bank32t, K, L), bank_lr_v16(d_bank32t, K, L), nv);
@@ -4573,7 +4642,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
     const size_t lds_screen = 4 * 8 + (size_t)R16_COPIES * r16t_stride(P, Lp) * 2 + (size_t)TRING * TG_BLK * 2 + units16 * 4 +
                               (((size_t)n_tiles(K) * NT * 2 + 15) & ~(size_t)15) + 2 * CSC_MAX_CONNECTIONS * 4 +
                               ((units16 + 15) & ~(size_t)15);
-    const size_t lds_lr = 32 + (size_t)ceil4(272 + Lp + 8) * 4 + (size_t)LR_AREA_F * 4 + MAX_SLABS * 4 + (units16 + 1) * 4 +
+    const size_t lds_lr = 32 + 2 * (size_t)R16_COPIES * r16t_stride(P, Lp) * 2 + (size_t)LR_PLANE_H * 2 + (units16 + 1) * 4 +
                           2 * CSC_MAX_CONNECTIONS * 4;
     const bool tiled16 = tiled && !(flags & CSC_FLAG_FP32_ONLY) && node_flags && mode == 0 && L <= 682 &&
                          lds16 <= 150 * 1024 && (long long)n_tiles(K) * nrb * NG <= MAX_UNITS16 && n_tiles(K) * NT <= 2 * MAX_UNITS16 &&
@@ -4620,7 +4689,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         const int span = timer_begin(st, d);
         a.flags = nullptr; a.S = S; a.signals = d_signals; a.ws[0] = ws[0]; a.ws[1] = ws[1];
         a.picks_only = 0; a.from_root = 0; a.sibling = -1;
-        a.lr_u32 = nullptr; a.lr_v16 = nullptr; a.lr_slack = nullptr; a.simatoms = nullptr; a.sa_w = 0;
+        a.lr_u16 = nullptr; a.lr_v16 = nullptr; a.lr_slack = nullptr; a.simatoms = nullptr; a.sa_w = 0;
         // level 0 in front of the chain kernel (every node of level 1 has one child): it only has to pick -- the chain
         // kernel builds a pick's node from the signal, so no child residual crosses HBM between the two launches
         const bool root_picks = lean && mode == 0 && d == 0 && max_sparsity > 1 && connections > 1 && ts.pw[1] >= ts.F[2];
@@ -4634,7 +4703,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
             int nsib = 0;
             for (int r = 0; r < connections; ++r)
                 if ((long long)r * ts.pw[d] < ts.F[d + 1]) ++nsib;
-            a.lr_u32 = lowrank ? bank_lr_u32(d_bank32t, K, L) : nullptr;
+            a.lr_u16 = lowrank ? reinterpret_cast<const _Float16*>(bank_lr_u32(d_bank32t, K, L)) : nullptr;
             a.lr_v16 = lowrank ? bank_lr_v16(d_bank32t, K, L) : nullptr;
             a.lr_slack = lowrank ? bank_lr_slack(d_bank32t, K, L) : nullptr;
             a.simatoms = simatoms ? bank_simatoms(d_bank32t, K, L) : nullptr;
