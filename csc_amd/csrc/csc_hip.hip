@@ -3044,9 +3044,9 @@ __device__ __forceinline__ void screen_blocks16(const LevelArgs& a, const _Float
         if (p.blk >= NT) { p.blk -= NT; if (++p.tile == ntile) { p.tile = 0; ++p.rb; } }
     };
     // slab range of a block: outside it the block is zero padding (brange[block + 9 tile] = s0 | s1 << 8, built by the caller)
-    // `need` (behind the low-rank screen): only the units marked there are multiplied; the others keep the bound they have
+    // `need` (behind the low-rank screen): only the 16-column blocks marked there are multiplied; the others keep the bound they have
     auto skipped = [&](const Pos& p) -> bool {
-        return need && !__builtin_amdgcn_readfirstlane((int)need[p.blk / NG + NG * (p.tile + ntile * p.rb)]);
+        return need && !__builtin_amdgcn_readfirstlane((int)need[p.blk + NT * (p.tile + ntile * p.rb)]);
     };
     auto block_range = [&](const Pos& p, int& s0, int& s1) {
         const int pk = __builtin_amdgcn_readfirstlane((int)brange[p.blk + NT * p.tile]);
@@ -3290,6 +3290,13 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
     unsigned* key = reinterpret_cast<unsigned*>(ring + TRING * TG_BLK);
     unsigned short* brange = reinterpret_cast<unsigned short*>(key + nunits);
     int* spick = reinterpret_cast<int*>(brange + ((NT * ntile + 1) & ~1));       // [2][CSC_MAX_CONNECTIONS]: pos, atom
+#if defined(CSC_PHASE_PROF) && defined(SCREEN16_PROF)
+    unsigned long long s16_t = __builtin_readcyclecounter();
+#define S16_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); \
+        atomicAdd(&g_prof[i][blockIdx.x % PROF_BUCKETS], n_ - s16_t); s16_t = n_; } } while (0)
+#else
+#define S16_STAMP(i)
+#endif
     const int Fd = a.ts.F[d];
     size_t s;
     int j;
@@ -3330,35 +3337,45 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
         rh[i] = (_Float16)(e < N ? rin[e] * sc : 0.0);
     }
     __syncthreads();
+    S16_STAMP(28);
     const _Float16* hi_all = reinterpret_cast<const _Float16*>(a.bank16);
     float* tab = screen_table(a, s, j, d, t);
     const unsigned char* need = nullptr;
     if (a.lr_u16) {
-        // behind screen_lr_kernel: its table holds, per unit, an upper bound (less e1) of what the unit can hold and, behind
-        // the units, a lower bound LB of the node's maximum.  A unit whose bound + e1 + band / 2 (the most the three-product
-        // sweep can find there) stays 2 bands below LB - band / 2 (the least its running maximum ends at) is never visited
-        // and keeps its bound; the single-term product tightens the others.
+        // behind screen_lr_kernel: its table holds, per 16-column block, an upper bound (less e1) of what the block can hold
+        // and, behind the blocks, a lower bound LB of the node's maximum.  A block whose bound + e1 + band / 2 (the most the
+        // three-product sweep can find there) stays 2 bands below LB - band / 2 (the least its running maximum ends at)
+        // cannot make its unit visited and keeps its bound; the single-term product tightens the others (a quarter of the
+        // blocks of the units in reach, a twentieth of all).  (One row block: block b = 9 tile + blk, unit b / 3.)
         unsigned char* nd = reinterpret_cast<unsigned char*>(spick + 2 * CSC_MAX_CONNECTIONS);
         const float am = sqrtf(am2);
         const float toacc = 64.f * split_scale(am2);
         const float e1 = (9.765625e-4f + 6.103515625e-05f + 1e-6f) * am + 2.98023223876953125e-08f * sqrtf((float)L) * (1.f + am);
         const float band = 2.f * ((EPS3_ACC + 9.5367431640625e-07f) * am + 1.862645149230957e-09f * sqrtf((float)L) * (1.f + am));
-        const float lb = tab[nunits];
+        const int nblk = NT * ntile;
+        const float lb = tab[nblk];
         for (int u = tid; u < nunits; u += WG) {
-            const float ub = tab[u];
+            float kept = -INFINITY;                                              // the unit's blocks that are not multiplied
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const float ub = tab[NG * u + i];
 #ifdef CSC_LR_CHECK
-            const bool skip = false;
+                const bool skip = false;
 #else
-            const bool skip = ub + (e1 + 0.5f * band) * toacc < lb - 2.5f * band * toacc;     // (false on NaN: multiplied)
+                const bool skip = ub + (e1 + 0.5f * band) * toacc < lb - 2.5f * band * toacc; // (false on NaN: multiplied)
 #endif
-            nd[u] = skip ? 0 : 1;
-            if (skip) key[u] = fkey(ub);
+                nd[NG * u + i] = skip ? 0 : 1;
+                if (skip) kept = fmaxf(kept, ub);
+            }
+            key[u] = fkey(kept);
         }
         need = nd;
         __syncthreads();
     }
+    S16_STAMP(29);
     if (rem) screen_blocks16<true>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring, t, spick, need);
     else screen_blocks16<false>(a, hi_all, key, brange, ntile, nslab, nrb, rh, R16T_CS, ring, t, spick, need);
+    S16_STAMP(30);
     __syncthreads();
 #ifdef CSC_LR_CHECK
     if (a.lr_u16) {
@@ -3368,10 +3385,24 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
         const float e1 = (9.765625e-4f + 6.103515625e-05f + 1e-6f) * am + 2.98023223876953125e-08f * sqrtf((float)L) * (1.f + am);
         float mx = -INFINITY;
         for (int u = 0; u < nunits; ++u) mx = fmaxf(mx, fkey_inv(key[u]));
-        const float lbc = tab[nunits];
+        const float lbc = tab[NT * ntile];
         for (int u = tid; u < nunits; u += WG) {
-            const float got = fkey_inv(key[u]), ub = tab[u];
+            const float got = fkey_inv(key[u]), ub = fmaxf(fmaxf(tab[NG * u], tab[NG * u + 1]), tab[NG * u + 2]);
             if (got > ub + 2.f * e1 * toacc) printf("LRCHK ub: s %d j %d d %d t %d unit %d single %g bound %g (e1 %g)\n", (int)s, j, d, t, u, got, ub, e1 * toacc);
+        }
+        if (tid == 0 && s < 24) {
+            // units with a block in reach of the lower bound, and the blocks themselves
+            const float band = 2.f * ((EPS3_ACC + 9.5367431640625e-07f) * am + 1.862645149230957e-09f * sqrtf((float)L) * (1.f + am));
+            int n0 = 0, n1 = 0;
+            for (int u = 0; u < nunits; ++u) {
+                bool un = false;
+                for (int i = 0; i < NG; ++i) {
+                    const bool nb = !(tab[NG * u + i] + (e1 + 0.5f * band) * toacc < lbc - 2.5f * band * toacc);
+                    n1 += nb; un |= nb;
+                }
+                n0 += un;
+            }
+            printf("LRNEED d %d t %d: units in reach %d, blocks multiplied %d of %d (lb %g max %g)\n", d, t, n0, n1, NG * n0, lbc, mx);
         }
         if (tid == 0 && mx < lbc - e1 * toacc) printf("LRCHK lb: s %d j %d d %d t %d max %g lb %g\n", (int)s, j, d, t, mx, lbc);
     }
@@ -3498,14 +3529,15 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
     const int nunits = ntile * NG;                                    // (one row block: the host checks P <= 272)
     const int CS = r16t_stride(P, nslab * SLAB);                      // halves per shifted copy of the residual window
     // LDS: red [4] doubles | rh, rl [8][CS] halves each, later plane 1 of T16 | plane 0 of T16 [272][32] halves |
-    // key [nunits + 1] (upper bounds, the node's lower bound) | spick [2][8]
+    // key [nblk + 1] (upper bound per 16-column block, the node's lower bound) | spick [2][8]
     double* red = lds_raw;
     _Float16* rh = reinterpret_cast<_Float16*>(red + 4);
     _Float16* rl = rh + R16_COPIES * CS;
     _Float16* t16p1 = rh;
     _Float16* t16p0 = rl + R16_COPIES * CS;
     unsigned* key = reinterpret_cast<unsigned*>(t16p0 + LR_PLANE_H);
-    int* spick = reinterpret_cast<int*>(key + nunits + 1);
+    const int nblk = ntile * NT;
+    int* spick = reinterpret_cast<int*>(key + nblk + 1);
     const int Fd = a.ts.F[d];
     size_t s;
     int j;
@@ -3523,7 +3555,7 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
     for (int i = tid; i < N; i += WG) { const double x = rin[i]; v = fma(x, x, v); }
     v = wave_sum(v);
     if (lane == 63) red[wave] = v;
-    for (int u = tid; u <= nunits; u += WG) key[u] = fkey(-INFINITY);
+    for (int u = tid; u <= nblk; u += WG) key[u] = fkey(-INFINITY);
     __syncthreads();
     const double rnorm2 = red[0] + red[1] + red[2] + red[3];
     const float am2 = *a.amax2, am = sqrtf(am2);
@@ -3540,7 +3572,7 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
         }
     }
     __syncthreads();
-#ifdef CSC_PHASE_PROF
+#if defined(CSC_PHASE_PROF) && !defined(SCREEN16_PROF)
     unsigned long long lr_t = __builtin_readcyclecounter();
 #define LR_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); \
         atomicAdd(&g_prof[i][blockIdx.x % PROF_BUCKETS], n_ - lr_t); lr_t = n_; } } while (0)
@@ -3571,11 +3603,7 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
             // early, the hi pair at the end of the k-step -- the other waves of the SIMD cover what latency is left)
             f16x8 bh[2], bl[2];
             auto load_u = [&](f16x8 (&B)[2], const _Float16* src, int ks) __attribute__((always_inline)) {
-#ifdef LR_EXP_NOLOADU
-                const int kk = min(ks, 0);
-#else
                 const int kk = min(ks, nks - 1);                       // (past the end: the last k-step again, unused)
-#endif
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     B[n] = *reinterpret_cast<const f16x8*>(src + ((size_t)kk * (LR_R / 16) + 2 * p + n) * 512);
@@ -3633,13 +3661,14 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
     // units u = (w >> 1), + 2, + 4, ... (three 16-column blocks each): 9 x 2 A fragments stay in registers (72 VGPRs; all
     // 17 x 2 with their 68 accumulators spilled at 256 registers, and every reload drained the fragments in flight), three
     // workgroups per CU.  B fragments (and the block's slack, one float per lane: the lane's column) come straight from L2,
-    // a block ahead, in two buffers.  Per block the lanes keep running bounds; the wave reduction and the LDS maximum come
-    // once per unit ------------------------------------------------------------------------------------------------------
-    const int nblk = ntile * NT, npad = ntile * CSC_TILE_COLS - K;
+    // a block ahead, in two buffers.  A block's upper bound is one ds_max_u32 of 16 lanes on the block's key (no full wave
+    // reduction on the vector pipe, which the products' issue shares); the lower bound stays a running value per lane ----
+    const int npad = ntile * CSC_TILE_COLS - K;
     const float toacc = 64.f * split_scale(am2);                      // units of ||r|| -> accumulator units
     const float e1 = (9.765625e-4f + 6.103515625e-05f + 1e-6f) * am + 2.98023223876953125e-08f * sqrtf((float)L) * (1.f + am);
     const int rows = min(P, 272);
     float lbmax = -INFINITY;
+    const unsigned key_off = (unsigned)(size_t)(lptr_t)key;           // LDS byte offset of the block keys
     static_assert(NT == 3 * NG, "a unit is three 16-column blocks");
     auto sweep = [&](auto half_tag) __attribute__((always_inline)) {
         constexpr int HALF = decltype(half_tag)::value;
@@ -3667,7 +3696,7 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
                 Bx[ks] = *reinterpret_cast<const f16x8*>(a.lr_v16 + ((size_t)bb * (LR_R / 32) + ks) * 512 + lane * 8);
             Sx = a.lr_slack[16 * bb + lr];                             // (column 144 tile + 16 blk + lr = 16 b + lr)
         };
-        auto block = [&](const f16x8 (&Bcur)[LR_R / 32], float Scur, int b, float& ubl, float& lbl) __attribute__((always_inline)) {
+        auto block = [&](const f16x8 (&Bcur)[LR_R / 32], float Scur, int b, float& lbl) __attribute__((always_inline)) {
             f32x4 acc[NS];
 #pragma unroll
             for (int i = 0; i < NS; ++i)
@@ -3732,48 +3761,48 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
                     lo = fminf(lo, hi);                               // (the unsuppressed maximum is no lower bound any more)
                 }
             }
-            // the lane's bounds: largest (suppressed) entry + slack (e1 comes off per unit); lower bound: - slack
-            ubl = fmaxf(ubl, colok ? hi + slk : -INFINITY);
+            // the lane's bounds: largest (suppressed) entry + slack (e1 comes off when the table is written; a NaN keeps
+            // the key of a NaN, above +inf: the block is multiplied); lower bound: - slack
+            // (two quad steps on the DPP network first, then one lane in four: the LDS serialises the lanes of a ds_max_u32
+            // on one address, and 64 of them per block kept it busy half the time.  Written out: atomicMax on one address
+            // would come back from the compiler as a loop over the lanes)
+            float ubq;
+            asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                         : "=&v"(ubq) : "v"(colok ? hi + slk : -INFINITY));
+            if ((lane & 3) == 0)
+                asm volatile("ds_max_u32 %0, %1" :: "v"(key_off + 4u * (unsigned)b), "v"(fkey(ubq)) : "memory");
             lbl = fmaxf(lbl, colok ? lo - slk : -INFINITY);
-        };
-        auto unit_done = [&](int u, float ubl) __attribute__((always_inline)) {
-            // upper bound of the unit (this half of its rows).  A NaN gives +inf.
-            float ub = wave_max(ubl) - e1 * toacc;
-            if (!(ub == ub)) ub = INFINITY;
-            if (lane == 63) atomicMax(&key[u], fkey(ub));
         };
         const int ufirst = wave >> 1;
         load_b(B0, S0, 3 * ufirst);
         load_b(B1, S1, 3 * ufirst + 1);
         for (int u = ufirst; u < nunits; u += 4) {                     // two units a turn: the buffers come round after six blocks
-            float ubl = -INFINITY;
-            block(B0, S0, 3 * u, ubl, lbmax);
+            block(B0, S0, 3 * u, lbmax);
             load_b(B0, S0, 3 * u + 2);
-            block(B1, S1, 3 * u + 1, ubl, lbmax);
+            block(B1, S1, 3 * u + 1, lbmax);
             load_b(B1, S1, 3 * u + 6);
-            block(B0, S0, 3 * u + 2, ubl, lbmax);
+            block(B0, S0, 3 * u + 2, lbmax);
             load_b(B0, S0, 3 * u + 7);
-            unit_done(u, ubl);
             if (u + 2 < nunits) {
-                ubl = -INFINITY;
-                block(B1, S1, 3 * u + 6, ubl, lbmax);
+                block(B1, S1, 3 * u + 6, lbmax);
                 load_b(B1, S1, 3 * u + 8);
-                block(B0, S0, 3 * u + 7, ubl, lbmax);
+                block(B0, S0, 3 * u + 7, lbmax);
                 load_b(B0, S0, 3 * u + 12);
-                block(B1, S1, 3 * u + 8, ubl, lbmax);
+                block(B1, S1, 3 * u + 8, lbmax);
                 load_b(B1, S1, 3 * u + 13);
-                unit_done(u + 2, ubl);
             }
         }
     };
     if (wave & 1) sweep(std::integral_constant<int, 1>{}); else sweep(std::integral_constant<int, 0>{});
     if (!(lbmax == lbmax)) lbmax = -INFINITY;
     lbmax = wave_max(lbmax);
-    if (lane == 63) atomicMax(&key[nunits], fkey(lbmax));
+    if (lane == 63) atomicMax(&key[nblk], fkey(lbmax));
     LR_STAMP(30);
     __syncthreads();
+    // the table: per 16-column block max(C~ + slack) - e1 | the node's lower bound
     float* tab = screen_table(a, s, j, d, t);
-    for (int u = tid; u <= nunits; u += WG) tab[u] = fkey_inv(key[u]);
+    for (int u = tid; u <= nblk; u += WG) tab[u] = fkey_inv(key[u]) - (u < nblk ? e1 * toacc : 0.f);
 }
 
 __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArgs a) {
@@ -4641,15 +4670,16 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
     const size_t units16 = (size_t)n_tiles(K) * nrb16 * NG;
     const size_t lds_screen = 4 * 8 + (size_t)R16_COPIES * r16t_stride(P, Lp) * 2 + (size_t)TRING * TG_BLK * 2 + units16 * 4 +
                               (((size_t)n_tiles(K) * NT * 2 + 15) & ~(size_t)15) + 2 * CSC_MAX_CONNECTIONS * 4 +
-                              ((units16 + 15) & ~(size_t)15);
-    const size_t lds_lr = 32 + 2 * (size_t)R16_COPIES * r16t_stride(P, Lp) * 2 + (size_t)LR_PLANE_H * 2 + (units16 + 1) * 4 +
+                              (((size_t)n_tiles(K) * NT + 15) & ~(size_t)15);
+    const size_t lds_lr = 32 + 2 * (size_t)R16_COPIES * r16t_stride(P, Lp) * 2 + (size_t)LR_PLANE_H * 2 + ((size_t)n_tiles(K) * NT + 1) * 4 +
                           2 * CSC_MAX_CONNECTIONS * 4;
     const bool tiled16 = tiled && !(flags & CSC_FLAG_FP32_ONLY) && node_flags && mode == 0 && L <= 682 &&
                          lds16 <= 150 * 1024 && (long long)n_tiles(K) * nrb * NG <= MAX_UNITS16 && n_tiles(K) * NT <= 2 * MAX_UNITS16 &&
                          lds_screen <= 100 * 1024 && (units16 + 1) * 4 <= (size_t)(N + TRI(max_sparsity) + max_sparsity) * 8;
+    const bool lr_table_fits = ((size_t)n_tiles(K) * NT + 1) * 4 <= (size_t)(N + TRI(max_sparsity) + max_sparsity) * 8;
     clear_stale_error();
     // the low-rank screen in front (the caller vouches for an installed section: csc_bank_lowrank): one row block only
-    const bool lowrank = tiled16 && (flags & CSC_FLAG_LOWRANK) && P >= CSC_TILE_ROWS && P <= 272 && lds_lr <= 80 * 1024;
+    const bool lowrank = tiled16 && (flags & CSC_FLAG_LOWRANK) && P >= CSC_TILE_ROWS && P <= 272 && lds_lr <= 80 * 1024 && lr_table_fits;
     // ... and the atom summary of d_sim_bits (csc_bank_simatoms, vouched for likewise): the later siblings' low-rank product
     // looks up similarity rows only for the columns the summary names
     const bool simatoms = lowrank && (flags & CSC_FLAG_SIMATOMS) && d_sim_bits;

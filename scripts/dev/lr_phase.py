@@ -16,4 +16,8 @@ torch.cuda.synchronize()
 L.csc_prof_read(buf, 1)
 v = np.array(list(buf), dtype=np.float64)
 n = 1024 * 13
-print("screen_lr_kernel per node (wave 0): T = R U %.0f clk, C~ = T V + bounds %.0f clk" % (v[29] / n, v[30] / n))
+if "--screen16" in sys.argv:      # library built with -DCSC_PHASE_PROF -DSCREEN16_PROF
+    n = 1024 * 15
+    print("screen16_kernel per node (wave 0): prologue %.0f clk, table + need %.0f clk, blocks %.0f clk" % (v[28] / n, v[29] / n, v[30] / n))
+else:
+    print("screen_lr_kernel per node (wave 0): T = R U %.0f clk, C~ = T V + bounds %.0f clk" % (v[29] / n, v[30] / n))
