@@ -121,6 +121,7 @@ struct LevelArgs {
     const float* lr_slack;    //   per bank column: what the low-rank product can miss of a correlation, in units of ||r||
     const uint32_t* simatoms; //   [K][sa_w] bit k' of row k: atom k' is similar to atom k at some shift (CSC_FLAG_SIMATOMS) | nullptr
     int sa_w;                 //   words per row of simatoms
+    const int* simrange;      //   [2][K] lowest / highest bit set anywhere in atom k's similarity rows (with simatoms) | nullptr
     int sibling;          // screen16_kernel / mmp_level_tiled16_kernel: the one child (sibling) of each node this launch selects
     int picks_only;       // level 0 ahead of the chain kernel: write the children's (pos, atom) and <atom, signal> only
     int from_root;        // chain kernel: build the level-1 node from the signal and the root level's pick
@@ -3500,18 +3501,33 @@ __global__ __launch_bounds__(64) void lr_slack_kernel(const double* __restrict__
     }
 }
 
-// Atom summary of a similarity table: bit k' of row k <=> the similarity row (k, k') has a bit set at any shift.
+// Atom summary of a similarity table: bit k' of row k <=> the similarity row (k, k') has a bit set at any shift; and, per
+// atom k, the lowest and the highest bit set in any of its rows (range[k], range[K + k]; preset to INT_MAX / -1): similar
+// means nearly aligned, so the band of shifts is narrow (config 3: 29 of 519 at most).
 // One thread per (k, k'), one word per half wave.
 __global__ __launch_bounds__(WG) void bank_simatoms_kernel(const uint32_t* __restrict__ sim_bits, int W, int K, int sa_w,
-                                                           uint32_t* __restrict__ out) {
+                                                           uint32_t* __restrict__ out, int* __restrict__ range) {
     const int k = blockIdx.y, kp = blockIdx.x * WG + threadIdx.x;
     uint32_t any = 0;
+    int lo = 0x7fffffff, hi = -1;
     if (kp < K) {
         const uint32_t* row = sim_bits + ((size_t)k * K + kp) * W;
-        for (int w = 0; w < W; ++w) any |= row[w];
+        for (int w = 0; w < W; ++w) {
+            const uint32_t x = row[w];
+            if (x) {
+                if (!any) lo = 32 * w + __builtin_ctz(x);
+                hi = 32 * w + 31 - __builtin_clz(x);
+            }
+            any |= x;
+        }
     }
     const unsigned long long m = __builtin_amdgcn_ballot_w64(any != 0);
     if ((threadIdx.x & 31) == 0 && (kp >> 5) < sa_w) out[(size_t)k * sa_w + (kp >> 5)] = (uint32_t)(m >> (threadIdx.x & 32));
+    if (m) {                                                         // (uniform per wave)
+        lo = wave_min(lo);
+        hi = -wave_min(-hi);
+        if ((threadIdx.x & 63) == 0) { atomicMin(&range[k], lo); atomicMax(&range[K + k], hi); }
+    }
 }
 
 // (SUPP: a later sibling's launch, for callers without the atom summary of their similarity table.  Its similarity-row
@@ -3529,7 +3545,8 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
     const int nunits = ntile * NG;                                    // (one row block: the host checks P <= 272)
     const int CS = r16t_stride(P, nslab * SLAB);                      // halves per shifted copy of the residual window
     // LDS: red [4] doubles | rh, rl [8][CS] halves each, later plane 1 of T16 | plane 0 of T16 [272][32] halves |
-    // key [nblk + 1] (upper bound per 16-column block, the node's lower bound) | spick [2][8]
+    // key [nblk + 1] (upper bound per 16-column block, the node's lower bound) | spick [5][8]: the earlier picks' position,
+    // atom, lowest and highest row they can suppress, first similarity word in use
     double* red = lds_raw;
     _Float16* rh = reinterpret_cast<_Float16*>(red + 4);
     _Float16* rl = rh + R16_COPIES * CS;
@@ -3547,8 +3564,16 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
     if (t > 0 && a.flags[s * Fd + j]) return;                                    // the node went to the fp32 kernel
     if (tid < t) {
         const size_t cid = s * a.NN + a.ts.off[d + 1] + j + (size_t)tid * a.ts.pw[d];
-        spick[tid] = a.node_pos[cid];
-        spick[CSC_MAX_CONNECTIONS + tid] = a.node_atom[cid];
+        const int pos = a.node_pos[cid], atom = a.node_atom[cid];
+        spick[tid] = pos;
+        spick[CSC_MAX_CONNECTIONS + tid] = atom;
+        // the band of shifts at which anything is similar to this atom (bit dp of a similarity row: shift dp - (P - 1)):
+        // the rows this pick can suppress, and the word its band starts in
+        int blo = 0, bhi = 2 * P - 2;
+        if (a.simrange && atom >= 0 && atom < K) { blo = max(a.simrange[atom], 0); bhi = min(a.simrange[K + atom], 2 * P - 2); }
+        spick[2 * CSC_MAX_CONNECTIONS + tid] = pos + blo - (P - 1);
+        spick[3 * CSC_MAX_CONNECTIONS + tid] = pos + bhi - (P - 1);
+        spick[4 * CSC_MAX_CONNECTIONS + tid] = ((bhi >> 5) - (blo >> 5) < 2) ? (blo >> 5) : -1;     // -1: a wide band, all words
     }
     const double* rin = a.resid_in + (d == 0 ? s * (size_t)N : (s * Fd + j) * (size_t)a.NS);
     double v = 0.0;
@@ -3670,8 +3695,10 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
     float lbmax = -INFINITY;
     const unsigned key_off = (unsigned)(size_t)(lptr_t)key;           // LDS byte offset of the block keys
     static_assert(NT == 3 * NG, "a unit is three 16-column blocks");
-    auto sweep = [&](auto half_tag) __attribute__((always_inline)) {
+    auto sweep = [&](auto half_tag, auto supp_tag) __attribute__((always_inline)) {
         constexpr int HALF = decltype(half_tag)::value;
+        constexpr bool SUPPNOW = decltype(supp_tag)::value;            // (SUPP, and an earlier pick can reach this half's rows)
+        constexpr int ROWLO = 144 * HALF, ROWHI = HALF ? 271 : 143;
         constexpr int NS = HALF ? 8 : 9;                               // row tiles 0 .. 8 | 9 .. 16
         f16x8 A[NS][LR_R / 32];
 #pragma unroll
@@ -3723,9 +3750,9 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
             };
             float lo = lane_max(), hi;
             hi = lo;
-            bool touched = SUPP && colok;
+            bool touched = SUPPNOW && colok;
             int atom = 0;
-            if (SUPP) {
+            if (SUPPNOW) {
                 // with the atom summary of the similarity table: only columns similar to an earlier pick at some shift
                 // have rows to look up, and most blocks hold none
                 const int tile = b / NT, blk = b - tile * NT;
@@ -3737,24 +3764,43 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
                     touched = touched && hit;
                 }
             }
-            if (SUPP && touched) {
+            if (SUPPNOW && touched) {
                 // a later sibling: entries similar to an earlier pick take the value 0 (as in screen_blocks16)
                 const int Wd = a.W;
                 bool any = false;
                 for (int q = 0; q < t; ++q) {
+                    const int qlo = spick[2 * CSC_MAX_CONNECTIONS + q], qhi = spick[3 * CSC_MAX_CONNECTIONS + q];
+                    if (qhi < ROWLO || qlo > ROWHI) continue;          // (uniform) this pick reaches none of this half's rows
                     const uint32_t* srow = a.sim_bits + ((size_t)spick[CSC_MAX_CONNECTIONS + q] * K + atom) * Wd;
-                    const int dpb = 144 * HALF + 4 * lq - spick[q] + P - 1;  // bit of (slot 0, rg 0) of this half; >= 0
-                    const int w0 = dpb >> 5, b0 = dpb & 31;
-                    uint32_t wd[6];
+                    const int w0 = spick[4 * CSC_MAX_CONNECTIONS + q];
+                    if (w0 >= 0) {
+                        // the band sits in two words: 64 bits from bit 32 w0; entry (slot i, rg) is bit sh0 + 16 i + rg of them
+                        const unsigned long long bits = (unsigned long long)srow[w0] |
+                                                        ((unsigned long long)(w0 + 1 < Wd ? srow[w0 + 1] : 0u) << 32);
+                        const int sh0 = ROWLO + 4 * lq - spick[q] + P - 1 - 32 * w0;
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) wd[i] = srow[min(w0 + i, Wd - 1)];
+                        for (int i = 0; i < NS; ++i) {
+                            if (ROWLO + 16 * i + 15 < qlo || ROWLO + 16 * i > qhi) continue;        // (uniform)
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) wd[i] = __funnelshift_r(wd[i], wd[i + 1], b0);
+                            for (int rg = 0; rg < 4; ++rg) {
+                                const int sh = sh0 + 16 * i + rg;
+                                if ((unsigned)sh < 64u && ((bits >> sh) & 1ull)) { if (acc[i][rg] > -1e29f) acc[i][rg] = 0.f; any = true; }
+                            }
+                        }
+                    } else {
+                        const int dpb = ROWLO + 4 * lq - spick[q] + P - 1;   // bit of (slot 0, rg 0) of this half; >= 0
+                        const int wf = dpb >> 5, b0 = dpb & 31;
+                        uint32_t wd[6];
 #pragma unroll
-                    for (int i = 0; i < NS; ++i)
+                        for (int i = 0; i < 6; ++i) wd[i] = srow[min(wf + i, Wd - 1)];
 #pragma unroll
-                        for (int rg = 0; rg < 4; ++rg)
-                            if ((wd[i >> 1] >> (16 * (i & 1) + rg)) & 1u) { if (acc[i][rg] > -1e29f) acc[i][rg] = 0.f; any = true; }
+                        for (int i = 0; i < 5; ++i) wd[i] = __funnelshift_r(wd[i], wd[i + 1], b0);
+#pragma unroll
+                        for (int i = 0; i < NS; ++i)
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg)
+                                if ((wd[i >> 1] >> (16 * (i & 1) + rg)) & 1u) { if (acc[i][rg] > -1e29f) acc[i][rg] = 0.f; any = true; }
+                    }
                 }
                 if (any) {
                     hi = lane_max();
@@ -3794,7 +3840,15 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
             }
         }
     };
-    if (wave & 1) sweep(std::integral_constant<int, 1>{}); else sweep(std::integral_constant<int, 0>{});
+    bool reach = false;                                                // (uniform) can an earlier pick suppress a row of this wave's half?
+    if (SUPP)
+        for (int q = 0; q < t; ++q)
+            reach |= !(spick[3 * CSC_MAX_CONNECTIONS + q] < 144 * (wave & 1) || spick[2 * CSC_MAX_CONNECTIONS + q] > ((wave & 1) ? 271 : 143));
+    if (SUPP && __builtin_amdgcn_readfirstlane((int)reach)) {
+        if (wave & 1) sweep(std::integral_constant<int, 1>{}, std::true_type{}); else sweep(std::integral_constant<int, 0>{}, std::true_type{});
+    } else {
+        if (wave & 1) sweep(std::integral_constant<int, 1>{}, std::false_type{}); else sweep(std::integral_constant<int, 0>{}, std::false_type{});
+    }
     if (!(lbmax == lbmax)) lbmax = -INFINITY;
     lbmax = wave_max(lbmax);
     if (lane == 63) atomicMax(&key[nblk], fkey(lbmax));
@@ -4377,7 +4431,7 @@ static size_t bank_lr_elems(int K, int L) {
 }
 // behind it: the atom summary of a similarity table (csc_bank_simatoms): K rows of sa_words(K) words
 static int sa_words(int K) { return (K + 31) / 32; }
-static size_t bank_sa_elems(int K) { return K <= CSC_TILE_COLS ? 0 : (size_t)K * sa_words(K); }
+static size_t bank_sa_elems(int K) { return K <= CSC_TILE_COLS ? 0 : (size_t)K * sa_words(K) + 2 * (size_t)K; }   // + the shift ranges
 static uint32_t* bank_simatoms(const float* d_bank32t, int K, int L) {
     return reinterpret_cast<uint32_t*>(const_cast<float*>(d_bank32t) + bank_base_elems(K, L) + bank_lr_elems(K, L));
 }
@@ -4459,8 +4513,13 @@ int csc_bank_simatoms(float* d_bank32t, int K, int L, const uint32_t* d_sim_bits
     if (K > 65535) FAIL(-11, "csc_bank_simatoms: dictionary too large (%d atoms)", K);
     hipStream_t st = (hipStream_t)stream;
     clear_stale_error();
+    uint32_t* out = bank_simatoms(d_bank32t, K, L);
+    int* range = reinterpret_cast<int*>(out + (size_t)K * sa_words(K));
+    hipError_t e = hipMemsetAsync(range, 0x7f, (size_t)K * 4, st);                 // (0x7f7f7f7f: above any bit index)
+    if (e == hipSuccess) e = hipMemsetAsync(range + K, 0xff, (size_t)K * 4, st);    // -1
+    if (e != hipSuccess) FAIL((int)e, "csc_bank_simatoms: hipMemsetAsync: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(bank_simatoms_kernel, dim3((unsigned)((K + WG - 1) / WG), (unsigned)K), dim3(WG), 0, st, d_sim_bits, W, K,
-                       sa_words(K), bank_simatoms(d_bank32t, K, L));
+                       sa_words(K), out, range);
     return launch_status("bank_simatoms_kernel");
 }
 
@@ -4672,7 +4731,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
                               (((size_t)n_tiles(K) * NT * 2 + 15) & ~(size_t)15) + 2 * CSC_MAX_CONNECTIONS * 4 +
                               (((size_t)n_tiles(K) * NT + 15) & ~(size_t)15);
     const size_t lds_lr = 32 + 2 * (size_t)R16_COPIES * r16t_stride(P, Lp) * 2 + (size_t)LR_PLANE_H * 2 + ((size_t)n_tiles(K) * NT + 1) * 4 +
-                          2 * CSC_MAX_CONNECTIONS * 4;
+                          5 * CSC_MAX_CONNECTIONS * 4;
     const bool tiled16 = tiled && !(flags & CSC_FLAG_FP32_ONLY) && node_flags && mode == 0 && L <= 682 &&
                          lds16 <= 150 * 1024 && (long long)n_tiles(K) * nrb * NG <= MAX_UNITS16 && n_tiles(K) * NT <= 2 * MAX_UNITS16 &&
                          lds_screen <= 100 * 1024 && (units16 + 1) * 4 <= (size_t)(N + TRI(max_sparsity) + max_sparsity) * 8;
@@ -4719,7 +4778,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         const int span = timer_begin(st, d);
         a.flags = nullptr; a.S = S; a.signals = d_signals; a.ws[0] = ws[0]; a.ws[1] = ws[1];
         a.picks_only = 0; a.from_root = 0; a.sibling = -1;
-        a.lr_u16 = nullptr; a.lr_v16 = nullptr; a.lr_slack = nullptr; a.simatoms = nullptr; a.sa_w = 0;
+        a.lr_u16 = nullptr; a.lr_v16 = nullptr; a.lr_slack = nullptr; a.simatoms = nullptr; a.sa_w = 0; a.simrange = nullptr;
         // level 0 in front of the chain kernel (every node of level 1 has one child): it only has to pick -- the chain
         // kernel builds a pick's node from the signal, so no child residual crosses HBM between the two launches
         const bool root_picks = lean && mode == 0 && d == 0 && max_sparsity > 1 && connections > 1 && ts.pw[1] >= ts.F[2];
@@ -4738,6 +4797,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
             a.lr_slack = lowrank ? bank_lr_slack(d_bank32t, K, L) : nullptr;
             a.simatoms = simatoms ? bank_simatoms(d_bank32t, K, L) : nullptr;
             a.sa_w = sa_words(K);
+            a.simrange = simatoms ? reinterpret_cast<const int*>(bank_simatoms(d_bank32t, K, L) + (size_t)K * sa_words(K)) : nullptr;
             for (int t = 0; t < nsib; ++t) {
                 a.sibling = t;
                 if (lowrank && t == 0) hipLaunchKernelGGL(screen_lr_kernel<false>, dim3((unsigned)grid), dim3(WG), lds_lr, st, a);

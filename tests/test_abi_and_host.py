@@ -56,9 +56,9 @@ def test_sizes_helpers():
     assert lib.csc_bank32_elems(143, 492) == 512 * 144 + 208 + 256 * 144 + 16 + 2 * 144 + 512 * 144
     # more than one tile: + the low-rank section (the basis as two-term fp16 fragments: 16 k-steps x 4 column blocks x 512
     # halves, hi and lo; per 16-column block of the bank 2 k-steps of fp16 coefficient fragments = 2 x 256 floats; one
-    # slack float per column) + ceil(K / 32) words of atom summary per atom
+    # slack float per column) + ceil(K / 32) words of atom summary per atom + lowest / highest similar shift per atom
     assert lib.csc_bank32_elems(145, 492) == (2 * (512 * 144 + 208 + 256 * 144) + 16 + 2 * 146 + 2 * 512 * 144
-                                              + 16 * 4 * 512 + 2 * 9 * 2 * 256 + 2 * 144 + 145 * 5)
+                                              + 16 * 4 * 512 + 2 * 9 * 2 * 256 + 2 * 144 + 145 * 5 + 2 * 145)
     assert lib.csc_sim_words(738, 492) == 2 * ((2 * 247 - 1 + 63) // 64)
     assert lib.csc_sim_words(100, 492) == 0
     # per frontier node: N residual samples + the packed Cholesky factor (15 doubles at depth 5)

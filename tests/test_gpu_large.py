@@ -329,12 +329,22 @@ def test_lowrank_screen_switches_give_identical_trees(large_dic):
             continue
         # the atom summary (the last K x ceil(K / 32) words of the image) of the table the launch above installed
         N = sigs.shape[1]
+        P = N - bank.L + 1
         W = bank.lib.csc_sim_words(N, bank.L)
         table = bank.similarity_table(N, thr).cpu().numpy().reshape(bank.K, bank.K, W)
         similar = (table != 0).any(axis=2)                              # [k][k']
         raw = bank.bank32t.cpu().numpy()
         sa_w = (bank.K + 31) // 32
-        got = raw[len(raw) - bank.K * sa_w:].view(np.uint32).reshape(bank.K, sa_w)
+        tail = raw[len(raw) - bank.K * (sa_w + 2):]
+        got = tail[:bank.K * sa_w].view(np.uint32).reshape(bank.K, sa_w)
         bits = np.unpackbits(got.view(np.uint8), axis=1, bitorder="little")[:, :bank.K].astype(bool)
         assert np.array_equal(bits, similar)
         assert similar.diagonal().all() and 0.01 < similar.mean() < 0.9
+        # ... and, behind it, the lowest / highest bit set in any of an atom's rows
+        rng_got = tail[bank.K * sa_w:].view(np.int32).reshape(2, bank.K)
+        anyrow = np.bitwise_or.reduce(table.view(np.uint32), axis=1)          # [k][W]
+        shifts = np.unpackbits(anyrow.view(np.uint8), axis=1, bitorder="little")
+        want_lo = shifts.argmax(axis=1)
+        want_hi = shifts.shape[1] - 1 - shifts[:, ::-1].argmax(axis=1)
+        assert np.array_equal(rng_got[0], want_lo) and np.array_equal(rng_got[1], want_hi)
+        assert (want_lo <= P - 1).all() and (want_hi >= P - 1).all()           # (an atom is similar to itself at shift 0)
