@@ -280,8 +280,9 @@ def other_configs(dic, d_sig2):
                            "branches 3 / max sparsity 5, 4096 device-generated constrained signals (N = 777, sparsity 4, SNR 10 dB)",
                            large, sig3, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY, 2, 64,
                            extra={"dictionary_build_and_pack_s": t_dict, "similarity_table_build_s": t_sim,
-                                  "note": "screen (single-term fp16) + three-product fp16 kernels, float64 re-score; the "
-                                          "issued flops depend on the units each selection visits (not counted here)"}))
+                                  "note": "low-rank screen (rank 64, rigorous per-atom bounds) + single-term fp16 screen of the "
+                                          "blocks in reach + three-product fp16 kernel, float64 re-score; the issued flops "
+                                          "depend on the blocks and units each selection visits (not counted here)"}))
     del sig3, large, lbank
     torch.cuda.empty_cache()
     return legs

@@ -60,18 +60,18 @@ int csc_bank_pack(const double* d_bank64, int K, int L, float* d_bank32t, void* 
  * section of the packed bank (csc_bank32_elems reserves it when K > 144): the basis as an fp32 tile, the atoms'
  * coefficients in fp16 and, per atom, the rigorous bound of what the rank-`rank` product can miss of a correlation.
  * csc_mmpdf_batch with CSC_FLAG_LOWRANK then screens a node's correlations through the basis first (34 matrix
- * instructions per 16 atoms instead of ~190) and multiplies in full only the tenth of the dictionary that bound cannot
- * exclude; results are identical with or without it. */
+ * instructions per 16 atoms instead of ~190) and multiplies in full only the twentieth of the dictionary that bound
+ * cannot exclude; results are identical with or without it. */
 int csc_lowrank_rank(void);
 int csc_bank_lowrank(float* d_bank32t, const double* d_bank64, int K, int L, const double* d_basis, int rank, void* stream);
 
 /* Atom summary of a similarity table for the low-rank screen (K > 144; no counterpart in the reference, which masks the
  * correlations of every sibling in full, src/csc/mmp.py:196-201).  d_sim_bits / W: a table of csc_similarity_table[_packed]
  * for this bank and its row length csc_sim_words(N, L).  Records in the packed bank, per pair of atoms, whether their
- * similarity row has a bit set at any shift (K x ceil(K / 32) words).  With CSC_FLAG_LOWRANK | CSC_FLAG_SIMATOMS and THAT
- * table, the low-rank screen of a node's second and later children reads similarity rows only for the columns the
- * summary names (most 16-column blocks hold none) instead of 6 words per column and earlier pick; results are identical
- * with or without it.  Call it again whenever the table passed to csc_mmpdf_batch changes (another threshold or signal
+ * similarity row has a bit set at any shift (K x ceil(K / 32) words) and, per atom, the lowest and the highest shift at
+ * which anything is similar to it (2 K words).  With CSC_FLAG_LOWRANK | CSC_FLAG_SIMATOMS and THAT table, the low-rank
+ * screen of a node's second and later children reads similarity words only for the columns and the shifts the summary
+ * names instead of 6 words per column and earlier pick; results are identical with or without it.  Call it again whenever the table passed to csc_mmpdf_batch changes (another threshold or signal
  * length). */
 int csc_bank_simatoms(float* d_bank32t, int K, int L, const uint32_t* d_sim_bits, int W, void* stream);
 
