@@ -3430,6 +3430,8 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
 // the single-term product only of the units whose low-rank bound can still reach that maximum (a tenth of them).
 #define LR_R 64                        // rank of the screen
 #define LR_PLANE_H (272 * 32)          // halves of one plane of T16 in LDS: [row][32 columns] (k-step of the second product)
+#define LR_CHUNK_U 51                  // later siblings: units per chunk of the sweep (the chunk's similarity bands wait in LDS)
+#define LR_CHUNK_C (LR_CHUNK_U * 3 * 16)   // = 2448 columns, at most 10 per thread
 
 // U16 [hi | lo][k-step][16-column block][lane][j] = the two fp16 terms of 64 U[l][i], l = 32 ks + 8 (lane >> 4) + j,
 // i = 16 block + (lane & 15): B fragments of v_mfma_f32_16x16x32_f16 (the scale keeps the lo terms of all but the
@@ -3534,7 +3536,7 @@ __global__ __launch_bounds__(WG) void bank_simatoms_kernel(const uint32_t* __res
 // loads sit behind a per-lane branch, and a loop with such a branch in it waits for every load in flight at each turn; a
 // kernel of its own, so that the first sibling's loop keeps its registers and waits by count)
 template <bool SUPP>
-__global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
+__global__ __launch_bounds__(WG, SUPP ? 2 : 3) void screen_lr_kernel(const LevelArgs a) {
     extern __shared__ double lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -3546,7 +3548,8 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
     const int CS = r16t_stride(P, nslab * SLAB);                      // halves per shifted copy of the residual window
     // LDS: red [4] doubles | rh, rl [8][CS] halves each, later plane 1 of T16 | plane 0 of T16 [272][32] halves |
     // key [nblk + 1] (upper bound per 16-column block, the node's lower bound) | spick [5][8]: the earlier picks' position,
-    // atom, lowest and highest row they can suppress, first similarity word in use
+    // atom, lowest and highest row they can suppress, first similarity word in use | simw [2][LR_CHUNK_C] (later siblings):
+    // the similarity band of every column of the current chunk, per earlier pick
     double* red = lds_raw;
     _Float16* rh = reinterpret_cast<_Float16*>(red + 4);
     _Float16* rl = rh + R16_COPIES * CS;
@@ -3555,6 +3558,7 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
     unsigned* key = reinterpret_cast<unsigned*>(t16p0 + LR_PLANE_H);
     const int nblk = ntile * NT;
     int* spick = reinterpret_cast<int*>(key + nblk + 1);
+    uint32_t* simw = reinterpret_cast<uint32_t*>(spick + 5 * CSC_MAX_CONNECTIONS);    // [2][LR_CHUNK_C] (later siblings, mode 2)
     const int Fd = a.ts.F[d];
     size_t s;
     int j;
@@ -3695,9 +3699,14 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
     float lbmax = -INFINITY;
     const unsigned key_off = (unsigned)(size_t)(lptr_t)key;           // LDS byte offset of the block keys
     static_assert(NT == 3 * NG, "a unit is three 16-column blocks");
-    auto sweep = [&](auto half_tag, auto supp_tag) __attribute__((always_inline)) {
+    auto sweep = [&](auto half_tag, auto mode_tag, int ubeg, int uend) __attribute__((always_inline)) {
         constexpr int HALF = decltype(half_tag)::value;
-        constexpr bool SUPPNOW = decltype(supp_tag)::value;            // (SUPP, and an earlier pick can reach this half's rows)
+        // 0: no suppression (first sibling, or no earlier pick reaches this half's rows); 1: similarity words looked up block
+        // by block (three dependent loads a block: any number of picks, any band of shifts); 2: the bands of the chunk's
+        // columns wait in LDS (gathered with every load in flight at once: at most two earlier picks, bands of at most 32
+        // shifts, the summary installed)
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool SUPPNOW = MODE == 1;
         constexpr int ROWLO = 144 * HALF, ROWHI = HALF ? 271 : 143;
         constexpr int NS = HALF ? 8 : 9;                               // row tiles 0 .. 8 | 9 .. 16
         f16x8 A[NS][LR_R / 32];
@@ -3713,6 +3722,18 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg)
                 if (CSC_TILE_ROWS + 4 * lq + rg >= rows) initl[rg] = -1e30f;
+        }
+        // (mode 2) per earlier pick, as scalars: the rows it can suppress, and whether any is in this half
+        int pk_lo[2] = {0, 0}, pk_hi[2] = {-1, -1};
+        bool pk_on[2] = {false, false};
+        if (MODE == 2) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (q >= t) continue;
+                pk_lo[q] = __builtin_amdgcn_readfirstlane(spick[2 * CSC_MAX_CONNECTIONS + q]);
+                pk_hi[q] = __builtin_amdgcn_readfirstlane(spick[3 * CSC_MAX_CONNECTIONS + q]);
+                pk_on[q] = !(pk_hi[q] < ROWLO || pk_lo[q] > ROWHI);
+            }
         }
         f16x8 B0[LR_R / 32], B1[LR_R / 32];
         float S0, S1;
@@ -3807,6 +3828,33 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
                     lo = fminf(lo, hi);                               // (the unsuppressed maximum is no lower bound any more)
                 }
             }
+            if (MODE == 2) {
+                const int cl = 16 * b + lr - 3 * 16 * ubeg;            // the column within the chunk
+                const uint32_t band0 = simw[cl], band1 = t > 1 ? simw[LR_CHUNK_C + cl] : 0u;
+                if (__builtin_amdgcn_ballot_w64(colok && (band0 | band1))) {    // (uniform) a column of the block is similar to a pick
+                    bool any = false;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (!pk_on[q]) continue;                       // (uniform) this pick reaches none of this half's rows
+                        const uint32_t band = colok ? (q ? band1 : band0) : 0u;  // bit i: row pk_lo + i of this column is suppressed
+                        const int rel0 = ROWLO + 4 * lq - pk_lo[q];
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            if (ROWLO + 16 * i + 15 < pk_lo[q] || ROWLO + 16 * i > pk_hi[q]) continue;   // (uniform: scalars)
+                            // the slot's four bits: band >> (rel0 + 16 i), for shifts of -3 .. 35
+                            const int sft = rel0 + 16 * i + 4;
+                            const uint32_t sb = (unsigned)sft < 36u ? (uint32_t)(((unsigned long long)band << 4) >> sft) : 0u;
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg)
+                                if ((sb >> rg) & 1u) { if (acc[i][rg] > -1e29f) acc[i][rg] = 0.f; any = true; }
+                        }
+                    }
+                    if (any) {
+                        hi = lane_max();
+                        lo = fminf(lo, hi);
+                    }
+                }
+            }
             // the lane's bounds: largest (suppressed) entry + slack (e1 comes off when the table is written; a NaN keeps
             // the key of a NaN, above +inf: the block is multiplied); lower bound: - slack
             // (two quad steps on the DPP network first, then one lane in four: the LDS serialises the lanes of a ds_max_u32
@@ -3820,17 +3868,17 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
                 asm volatile("ds_max_u32 %0, %1" :: "v"(key_off + 4u * (unsigned)b), "v"(fkey(ubq)) : "memory");
             lbl = fmaxf(lbl, colok ? lo - slk : -INFINITY);
         };
-        const int ufirst = wave >> 1;
+        const int ufirst = ubeg + (((wave >> 1) ^ ubeg) & 1);          // the wave pair's first unit of [ubeg, uend)
         load_b(B0, S0, 3 * ufirst);
         load_b(B1, S1, 3 * ufirst + 1);
-        for (int u = ufirst; u < nunits; u += 4) {                     // two units a turn: the buffers come round after six blocks
+        for (int u = ufirst; u < uend; u += 4) {                       // two units a turn: the buffers come round after six blocks
             block(B0, S0, 3 * u, lbmax);
             load_b(B0, S0, 3 * u + 2);
             block(B1, S1, 3 * u + 1, lbmax);
             load_b(B1, S1, 3 * u + 6);
             block(B0, S0, 3 * u + 2, lbmax);
             load_b(B0, S0, 3 * u + 7);
-            if (u + 2 < nunits) {
+            if (u + 2 < uend) {
                 block(B1, S1, 3 * u + 6, lbmax);
                 load_b(B1, S1, 3 * u + 8);
                 block(B0, S0, 3 * u + 7, lbmax);
@@ -3844,10 +3892,71 @@ __global__ __launch_bounds__(WG, 3) void screen_lr_kernel(const LevelArgs a) {
     if (SUPP)
         for (int q = 0; q < t; ++q)
             reach |= !(spick[3 * CSC_MAX_CONNECTIONS + q] < 144 * (wave & 1) || spick[2 * CSC_MAX_CONNECTIONS + q] > ((wave & 1) ? 271 : 143));
-    if (SUPP && __builtin_amdgcn_readfirstlane((int)reach)) {
-        if (wave & 1) sweep(std::integral_constant<int, 1>{}, std::true_type{}); else sweep(std::integral_constant<int, 0>{}, std::true_type{});
+    bool gathered = SUPP && a.simatoms && t <= 2;                      // (uniform) mode 2's conditions
+    if (SUPP)
+        for (int q = 0; q < t; ++q)
+            gathered = gathered && spick[3 * CSC_MAX_CONNECTIONS + q] - spick[2 * CSC_MAX_CONNECTIONS + q] < 32;
+    const bool reaches = SUPP && __builtin_amdgcn_readfirstlane((int)reach);
+    if (SUPP && __builtin_amdgcn_readfirstlane((int)gathered)) {
+        // chunk by chunk: the similarity band (the <= 32 shifts from the first one anything is similar at) of every column
+        // of the chunk, per earlier pick, gathered with all loads of a stage in flight at once -- atoms, summary bits,
+        // similarity words: three round trips per chunk instead of three per block
+        for (int ubeg = 0; ubeg < nunits; ubeg += LR_CHUNK_U) {
+            const int uend = min(nunits, ubeg + LR_CHUNK_U);
+            const int cbeg = 3 * 16 * ubeg, cend = 3 * 16 * uend;
+            constexpr int PER = (LR_CHUNK_C + WG - 1) / WG;
+            int atoms[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int c = cbeg + tid + WG * i;
+                atoms[i] = c < cend ? a.meta[(size_t)(c / CSC_TILE_COLS) * META_INTS + c % CSC_TILE_COLS] : -1;
+            }
+            uint32_t sa[PER][2];
+#pragma unroll
+            for (int i = 0; i < PER; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    sa[i][q] = q < t ? a.simatoms[(size_t)spick[CSC_MAX_CONNECTIONS + q] * a.sa_w + (max(atoms[i], 0) >> 5)] : 0u;
+            uint32_t w[PER][2][2];
+#pragma unroll
+            for (int i = 0; i < PER; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const bool hit = q < t && atoms[i] >= 0 && ((sa[i][q] >> (atoms[i] & 31)) & 1u);
+                    w[i][q][0] = 0u; w[i][q][1] = 0u;
+                    if (hit) {
+                        const int blo = spick[2 * CSC_MAX_CONNECTIONS + q] - spick[q] + P - 1;   // the band's first bit
+                        const uint32_t* srow = a.sim_bits + ((size_t)spick[CSC_MAX_CONNECTIONS + q] * K + atoms[i]) * a.W;
+                        w[i][q][0] = srow[blo >> 5];
+                        w[i][q][1] = (blo >> 5) + 1 < a.W ? srow[(blo >> 5) + 1] : 0u;
+                    }
+                }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int cl = tid + WG * i;
+                if (cl < LR_CHUNK_C)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int blo = q < t ? spick[2 * CSC_MAX_CONNECTIONS + q] - spick[q] + P - 1 : 0;
+                        simw[q * LR_CHUNK_C + cl] = (uint32_t)((((unsigned long long)w[i][q][1] << 32) | w[i][q][0]) >> (blo & 31));
+                    }
+            }
+            __syncthreads();
+            if (reaches) {
+                if (wave & 1) sweep(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, ubeg, uend);
+                else sweep(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, ubeg, uend);
+            } else {
+                if (wave & 1) sweep(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, ubeg, uend);
+                else sweep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ubeg, uend);
+            }
+            __syncthreads();                                           // (the next chunk's bands go where this one's are)
+        }
+    } else if (reaches) {
+        if (wave & 1) sweep(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, 0, nunits);
+        else sweep(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, 0, nunits);
     } else {
-        if (wave & 1) sweep(std::integral_constant<int, 1>{}, std::false_type{}); else sweep(std::integral_constant<int, 0>{}, std::false_type{});
+        if (wave & 1) sweep(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, 0, nunits);
+        else sweep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, nunits);
     }
     if (!(lbmax == lbmax)) lbmax = -INFINITY;
     lbmax = wave_max(lbmax);
@@ -4732,6 +4841,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
                               (((size_t)n_tiles(K) * NT + 15) & ~(size_t)15);
     const size_t lds_lr = 32 + 2 * (size_t)R16_COPIES * r16t_stride(P, Lp) * 2 + (size_t)LR_PLANE_H * 2 + ((size_t)n_tiles(K) * NT + 1) * 4 +
                           5 * CSC_MAX_CONNECTIONS * 4;
+    const size_t lds_lr_supp = lds_lr + 2 * (size_t)LR_CHUNK_C * 4;     // later siblings: + the chunk's similarity bands
     const bool tiled16 = tiled && !(flags & CSC_FLAG_FP32_ONLY) && node_flags && mode == 0 && L <= 682 &&
                          lds16 <= 150 * 1024 && (long long)n_tiles(K) * nrb * NG <= MAX_UNITS16 && n_tiles(K) * NT <= 2 * MAX_UNITS16 &&
                          lds_screen <= 100 * 1024 && (units16 + 1) * 4 <= (size_t)(N + TRI(max_sparsity) + max_sparsity) * 8;
@@ -4747,7 +4857,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
         hipFuncSetAttribute((const void*)screen16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_screen);
         if (lowrank) {
             hipFuncSetAttribute((const void*)screen_lr_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lr);
-            hipFuncSetAttribute((const void*)screen_lr_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lr);
+            hipFuncSetAttribute((const void*)screen_lr_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lr_supp);
         }
     }
     hipFuncSetAttribute(tiled ? (const void*)mmp_level_tiled_kernel : (const void*)mmp_level_kernel,
@@ -4801,7 +4911,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
             for (int t = 0; t < nsib; ++t) {
                 a.sibling = t;
                 if (lowrank && t == 0) hipLaunchKernelGGL(screen_lr_kernel<false>, dim3((unsigned)grid), dim3(WG), lds_lr, st, a);
-                else if (lowrank) hipLaunchKernelGGL(screen_lr_kernel<true>, dim3((unsigned)grid), dim3(WG), lds_lr, st, a);
+                else if (lowrank) hipLaunchKernelGGL(screen_lr_kernel<true>, dim3((unsigned)grid), dim3(WG), lds_lr_supp, st, a);
 
                 hipLaunchKernelGGL(screen16_kernel, dim3((unsigned)grid), dim3(WG), lds_screen, st, a);
                 hipLaunchKernelGGL(mmp_level_tiled16_kernel, dim3((unsigned)grid), dim3(WG), lds16, st, a);
