@@ -4848,7 +4848,7 @@ static int run_levels(int mode, const float* d_bank32t, const double* d_bank64, 
     const bool lr_table_fits = ((size_t)n_tiles(K) * NT + 1) * 4 <= (size_t)(N + TRI(max_sparsity) + max_sparsity) * 8;
     clear_stale_error();
     // the low-rank screen in front (the caller vouches for an installed section: csc_bank_lowrank): one row block only
-    const bool lowrank = tiled16 && (flags & CSC_FLAG_LOWRANK) && P >= CSC_TILE_ROWS && P <= 272 && lds_lr <= 80 * 1024 && lr_table_fits;
+    const bool lowrank = tiled16 && (flags & CSC_FLAG_LOWRANK) && P >= CSC_TILE_ROWS && P <= 272 && lds_lr_supp <= 100 * 1024 && lr_table_fits;
     // ... and the atom summary of d_sim_bits (csc_bank_simatoms, vouched for likewise): the later siblings' low-rank product
     // looks up similarity rows only for the columns the summary names
     const bool simatoms = lowrank && (flags & CSC_FLAG_SIMATOMS) && d_sim_bits;

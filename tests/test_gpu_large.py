@@ -293,8 +293,8 @@ def test_lowrank_screen_switches_give_identical_trees(large_dic):
     (csc_bank_simatoms, CSC_FLAG_SIMATOMS) change which units are multiplied and which rows are looked up, never what is
     selected: with both, with the screen alone and with neither, every output is the same -- on BASELINE config 3's
     dictionary (golden signals, siblings at the root) and on a 330-atom dictionary with 3 connections / 10 branches
-    (siblings on every level, the last one included, where the siblings share one table row), P = 260 and 272 (remainder
-    tile of 4 and of 16 rows).  The summary itself is checked against a restatement from the table."""
+    (siblings on every level, the last one included, where the siblings share one table row), P = 260, 272 and 256
+    (remainder tile of 4, of 16 and of no rows).  The summary itself is checked against a restatement from the table."""
     import torch
     import csc_amd
     z = np.load(os.path.join(GOLDEN, "large.npz"))
@@ -303,12 +303,13 @@ def test_lowrank_screen_switches_give_identical_trees(large_dic):
     rng = np.random.default_rng(23)
     L2 = d2.getAtomsLength()
     bank2 = d2.getLocalDictionary()
-    for P in (260, 272):
+    for P in (260, 272, 256):
         sig = 0.02 * rng.standard_normal((24, L2 + P - 1))
         for srow in sig:
             for _ in range(3):
                 srow[rng.integers(0, P):][:L2] += rng.uniform(0.5, 1.5) * bank2[rng.integers(len(bank2))]
         cases.append((d2, sig, (4, 3, 10, 0.7)))
+    cases.append((d2, cases[1][1][:12], (3, 4, 16, 0.7)))             # a fourth child: more earlier picks than the gathered bands take
     names = ("node_pos", "node_atom", "node_mse", "node_coef", "rec_mse", "rec_leaf", "rec_sel")
     for dic, sigs, (Kx, c, B, thr) in cases:
         bank = dic.device_bank()
