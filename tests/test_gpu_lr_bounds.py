@@ -26,10 +26,10 @@ root, golden = sys.argv[1:3]
 sys.path.insert(0, root)
 import torch
 import csc_amd
-assert any(os.path.basename(os.environ["CSC_HIP_LIB"]) in line for line in open("/proc/self/maps"))
 large = csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.0005), np.arange(0.010, 0.036, 0.0003), [1])
 z = np.load(os.path.join(golden, "large.npz"))
 bank = large.device_bank()
+assert any(os.path.basename(os.environ["CSC_HIP_LIB"]) in line for line in open("/proc/self/maps"))
 assert bank.lowrank and bank.simatoms
 bank.mmpdf_batch(z["signals"], 5, 3, 3, 0.8, want_coef=False)
 d2 = csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.0025), np.arange(0.010, 0.036, 0.0018), [1])
