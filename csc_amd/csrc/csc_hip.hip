@@ -2725,6 +2725,23 @@ static __host__ __device__ inline int r16t_stride(int P, int Lp) {
     const int need = (rem ? nrb_all - 1 : nrb_all) * CSC_TILE_ROWS + 16 + Lp + SLAB;
     return ((need - 32 + 127) / 128) * 128 + 32;
 }
+// The residual, scaled by sc, as fp16 (rh) or as a two-term fp16 number (rh + rl) in R16_COPIES shifted copies of CS halves:
+// copy c holds element m + c at m.  Every thread converts its elements once and stores them to the eight places.
+__device__ __forceinline__ void build_r16t_copies(const double* r, int N, double sc, _Float16* rh, _Float16* rl, int CS) {
+    for (int e = threadIdx.x; e < CS + R16_COPIES - 1; e += WG) {
+        const double x = e < N ? r[e] * sc : 0.0;
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (double)h);
+#pragma unroll
+        for (int c = 0; c < R16_COPIES; ++c) {
+            const int m = e - c;
+            if (m >= 0 && m < CS) {
+                rh[c * CS + m] = h;
+                if (rl) rl[c * CS + m] = l;
+            }
+        }
+    }
+}
 #define TRING 4                        // group-slabs in the ring: one being multiplied, one landed, two copies in flight
 #define TG_BLK (2 * NG * BLKF)         // halves of one group-slab: 3 hi blocks, 3 lo blocks
 #define EPS3_ACC 1.220703125e-04f      // 2^-13
@@ -3333,10 +3350,7 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
     // order: the window here is a little wider, so that a node it takes always finds its table written)
     if (!(am2 > 1e-6f && am2 < 1e4f && rnorm2 > 0.5e-30 && rnorm2 < 2e30)) return;
     const double sc = 64.0 / sqrt(rnorm2);
-    for (int i = tid; i < R16_COPIES * R16T_CS; i += WG) {
-        const int c = i / R16T_CS, e = i - c * R16T_CS + c;
-        rh[i] = (_Float16)(e < N ? rin[e] * sc : 0.0);
-    }
+    build_r16t_copies(rin, N, sc, rh, nullptr, R16T_CS);
     __syncthreads();
     S16_STAMP(28);
     const _Float16* hi_all = reinterpret_cast<const _Float16*>(a.bank16);
@@ -3592,13 +3606,7 @@ __global__ __launch_bounds__(WG, SUPP ? 2 : 3) void screen_lr_kernel(const Level
     {
         // the residual as a two-term fp16 number, scaled to norm 64, in 8 shifted copies each (as mmp_level_tiled16_kernel)
         const double sc = 64.0 / sqrt(rnorm2);
-        for (int i = tid; i < R16_COPIES * CS; i += WG) {
-            const int c = i / CS, e = i - c * CS + c;
-            const double x = e < N ? rin[e] * sc : 0.0;
-            const _Float16 h = (_Float16)x;
-            rh[i] = h;
-            rl[i] = (_Float16)(x - (double)h);
-        }
+        build_r16t_copies(rin, N, sc, rh, rl, CS);
     }
     __syncthreads();
 #if defined(CSC_PHASE_PROF) && !defined(SCREEN16_PROF)
@@ -4027,13 +4035,7 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
     {
         // the residual as a two-term fp16 number, scaled to norm 64, in 8 shifted copies each
         const double sc = 64.0 / sqrt(rnorm2);
-        for (int i = tid; i < R16_COPIES * R16T_CS; i += WG) {
-            const int c = i / R16T_CS, e = i - c * R16T_CS + c;
-            const double x = e < N ? r64[e] * sc : 0.0;
-            const _Float16 h = (_Float16)x;
-            rh[i] = h;
-            rl[i] = (_Float16)(x - (double)h);
-        }
+        build_r16t_copies(r64, N, sc, rh, rl, R16T_CS);
     }
     __syncthreads();
     PROF_MARK(0);
