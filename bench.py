@@ -301,6 +301,9 @@ def main():
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo: CPU rehearsal of the multi-rank control flow (tests/test_bench_world2.py injects a CPU "
                          "stand-in for the device bank); no kernels, no roofline")
+    ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
+                    help="HIP streams the timed steps alternate between (2: the root level of one batch runs under the "
+                         "chains of the batch before it; 1: one batch after the other)")
     ap.add_argument("--fp32-only", action="store_true",
                     help="diagnostic (profiling the fp32 leg): the timed loop itself runs with CSC_FLAG_FP32_ONLY")
     a = ap.parse_args()
@@ -383,10 +386,21 @@ def main():
         if (use_dist and rank == 0) else [None, None]
     pending = [None, None]
 
+    # The steps alternate between two HIP streams (--streams 2, the default): every batch is a chain of dependent
+    # launches -- the root level on 2 workgroups per CU, then the chains on 5 -- whose first and last workgroups leave CUs
+    # idle; with the next batch on the other stream its root level fills them.  Step k uses stream k % 2, receive-buffer
+    # set k % 2 and (through torch's allocator) its own workspace and outputs; all of it is waited for before the clock stops.
+    import contextlib
+    streams = [torch.cuda.Stream(dev) for _ in range(a.streams)] if gpu else []
+
+    def on_stream(k):
+        return torch.cuda.stream(streams[k % len(streams)]) if len(streams) > 1 else contextlib.nullcontext()
+
     def step(k):
         """One step: wait for the gather that last used this buffer set, solve, enqueue this step's gather."""
-        rows = pending[k & 1].wait() if pending[k & 1] is not None else None
-        pending[k & 1] = solve(d_sig, shard_sizes=shard_sizes, recv=recv[k & 1], async_gather=True)
+        with on_stream(k):
+            rows = pending[k & 1].wait() if pending[k & 1] is not None else None
+            pending[k & 1] = solve(d_sig, shard_sizes=shard_sizes, recv=recv[k & 1], async_gather=True)
         return rows
 
     def drain():
@@ -434,6 +448,26 @@ def main():
         assert torch.equal(rows[:S].cpu(), host_rec), "gathered records differ from the single-call records"
     own, stats_t = bank.mmpdf_records(d_sig, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY)
     stats = stats_t.cpu().numpy().tolist()
+
+    # the same batches on ONE stream (outside the timed region, no collective): the level kernels' launch times when
+    # nothing else shares the chip with them -- the roofline of the kernels themselves, next to the timed region's
+    spans_1, one_elapsed, steps_1 = [], 0.0, 0
+    if gpu and len(streams) > 1 and rank == 0:
+        out_1 = bank.mmpdf_launch(d_sig, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY, want_coef=False)
+        steps_1 = max(2, min(300, a.steps))
+        for _ in range(min(50, steps_1)):
+            bank.mmpdf_launch(d_sig, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY, want_coef=False, out=out_1)
+        torch.cuda.synchronize(dev)
+        timer_1 = _lib.LevelTimer(capacity=steps_1 * MAX_SPARSITY)
+        t0 = time.perf_counter()
+        with timer_1:
+            for _ in range(steps_1):
+                bank.mmpdf_launch(d_sig, MAX_SPARSITY, CONNECTIONS, BRANCHES, DISSIMILARITY, want_coef=False, out=out_1)
+            torch.cuda.synchronize(dev)
+        one_elapsed = time.perf_counter() - t0
+        spans_1 = timer_1.read()
+        timer_1.close()
+        del out_1
 
     # the same batch correlated in fp32 only (CSC_FLAG_FP32_ONLY): the "% of fp32 MFMA peak" leg of
     # BASELINE.json's metric; outside the timed region, no collective
@@ -517,6 +551,21 @@ def main():
         # ---- algorithmic flops: every selecting node correlates its residual with all
         # K atoms at all P shifts, 2*P*K*L flops, n_sel = 13 nodes per signal over the 5 tree levels
         flops_per_launch = S * flops_per_signal / MAX_SPARSITY
+        # With two streams a launch of the timed region shares the chip with the other stream's launches (and waits for
+        # its workgroup slots): its span is not the kernel's own time.  The roofline of the KERNELS is then taken from the
+        # single-stream leg behind the timed region (the same batches, `roofline.measured_in`); the timed region's own
+        # spans and its overall rate are reported beside it (`roofline.timed_region`).
+        timed_region = None
+        if spans_1:
+            timed_region = {"launch_ms_avg": launch_ms, "launch_ms_by_level": per_level, "launches_timed": len(spans),
+                            "dense_equivalent_tflops": world * S * a.steps * flops_per_signal / elapsed / 1e12 / world,
+                            "note": "HIP-event spans of the timed region's launches (two streams: they overlap, their sum "
+                                    "exceeds the elapsed time) and the algorithmic flops of all its steps over the "
+                                    "elapsed time, per GPU"}
+            timed_region["dense_equivalent_over_fp16_peak"] = timed_region["dense_equivalent_tflops"] / FP16_MFMA_PEAK_TFLOPS
+            launch_ms = float(sum(ms for _, ms in spans_1)) / (steps_1 * MAX_SPARSITY)
+            per_level = {str(d): float(np.mean([ms for lv, ms in spans_1 if lv == d]))
+                         for d in sorted({lv for lv, _ in spans_1})}
         achieved = flops_per_launch / (launch_ms * 1e-3) / 1e12
         # MFMA flops actually issued by the fp16 filter (issued_fp16_flops_per_signal: the root on the register-resident
         # kernel, the chains' nodes on the chain kernel with per-tile slab ranges)
@@ -577,7 +626,12 @@ def main():
                                        "sets and runs under the next step's solve; every gather is waited for before "
                                        "the clock stops (the per-pass form with ONE gather per 125 000 signals per "
                                        "rank is `config5`)")
-                       if world > 1 else "single GPU (ZSDictionary.mmpdfSparVarRecords)"},
+                       if world > 1 else "single GPU (ZSDictionary.mmpdfSparVarRecords)",
+                       "streams": len(streams),
+                       "overlap": ("the steps alternate between two HIP streams: a batch is a chain of dependent launches "
+                                   "(root level, then the chains), and the next batch's root level runs in what the "
+                                   "chains' last workgroups leave idle; every step's work is complete before the clock stops")
+                       if len(streams) > 1 else "none: one batch after the other on one stream"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP16_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "hbm_gb_per_s": hbm_gbs, "hbm_peak_gb_per_s": HBM_PEAK_GBS,
@@ -585,12 +639,21 @@ def main():
                          "issued_tflops": issued16, "issued_frac": issued16 / FP16_MFMA_PEAK_TFLOPS,
                          "kernel": "mmp_level_lean_kernel (levels 1-4, one launch) + mmp_level_kernel (level 0)",
                          "launch_ms_avg": launch_ms, "launch_ms_by_level": per_level,
+                         "measured_in": ("single-stream leg: %d steps of the same batch, one after the other on one stream, "
+                                         "behind the timed region (%.3f ms per step, %.0f signals/s); "
+                                         "profiles/r03_kernel_stats.csv is rocprofv3 of `bench.py --streams 1`"
+                                         % (steps_1, one_elapsed / steps_1 * 1e3, S * steps_1 / one_elapsed))
+                         if spans_1 else "the timed region",
+                         "timed_region": timed_region,
                          "flops_per_launch": flops_per_launch, "flops_per_signal": flops_per_signal,
-                         "launches_timed": len(spans),
+                         "launches_timed": len(spans_1) if spans_1 else len(spans),
                          "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "blocks_per_node": {"register_resident_kernel": blocks16, "chain_kernel": blocks_chain},
                          "of_dense_blocks": nslab * 9,
-                         "note": "correlations on the fp16 matrix cores as a filter (arithmetic dtype f16, fp32 "
+                         "note": ("`achieved` / `frac` / `launch_ms_*` are the level kernels' own launch times (see "
+                                  "`measured_in`): in the timed region two streams share the chip; "
+                                  if spans_1 else "") +
+                                 "correlations on the fp16 matrix cores as a filter (arithmetic dtype f16, fp32 "
                                  "accumulation), selection decided by a float64 re-score of the entries in the "
                                  "fp16 rounding band; `achieved` / `frac` count the reference's dense 2*P*K*L flops "
                                  "per selecting node (algorithmic flops per launch / measured launch time), "
