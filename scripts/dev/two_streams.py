@@ -8,7 +8,7 @@ d = csc_amd.ZSDictionary.from_values(np.arange(0.005, 0.06, 0.005), np.arange(0.
 bank = d.device_bank()
 S = 3200
 sig, _ = bank.generate(np.full(S, 4, np.int32), np.full(S, 10.0), 738, 10, 0.75, seed=1)
-outs = [bank.mmpdf_launch(sig, 5, 3, 3, 0.8, want_coef=False) for _ in range(2)]
+outs = [bank.mmpdf_launch(sig, 5, 3, 3, 0.8, want_coef=False) for _ in range(4)]
 torch.cuda.synchronize()
 def run(nstream, steps=600):
     streams = [torch.cuda.Stream() for _ in range(nstream)]
@@ -17,9 +17,9 @@ def run(nstream, steps=600):
         t0 = time.perf_counter()
         for k in range(steps):
             with torch.cuda.stream(streams[k % nstream]):
-                bank.mmpdf_launch(sig, 5, 3, 3, 0.8, want_coef=False, out=outs[k % 2])
+                bank.mmpdf_launch(sig, 5, 3, 3, 0.8, want_coef=False, out=outs[k % nstream])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     return S * steps / dt
-for n in (1, 2, 1, 2):
+for n in (1, 2, 3, 4, 2, 3):
     print(n, "stream(s): %.3f M signals/s" % (run(n) / 1e6))
