@@ -3335,13 +3335,22 @@ __global__ __launch_bounds__(WG, 3) void screen16_kernel(const LevelArgs a) {
     v = wave_sum(v);
     if (lane == 63) red[wave] = v;
     for (int u = tid; u < nunits; u += WG) key[u] = fkey(-INFINITY);
-    for (int e = tid; e < NT * ntile; e += WG) {                      // slab range of every 16-column block (s0 | s1 << 8)
-        const int32_t* mk = a.meta + (size_t)(e / NT) * META_INTS + CSC_TILE_COLS;
-        const int blk = e % NT;
-        int lo = nslab, hi = 0;
-        for (int q = 0; q < nslab; ++q)
-            if (((uint32_t)mk[q] >> blk) & 1u) { lo = min(lo, q); hi = q + 1; }
-        brange[e] = (unsigned short)(min(lo, hi) | (hi << 8));
+    // slab range of every 16-column block (s0 | s1 << 8), from the tiles' slab masks: the masks first, all loads at once,
+    // into the ring (idle until the blocks are swept) -- read one by one inside the loop over the slabs each was an L2
+    // round trip of its own, 17 in a row
+    {
+        uint32_t* lmask = reinterpret_cast<uint32_t*>(ring);
+        for (int i = tid; i < ntile * nslab; i += WG)
+            lmask[i] = (uint32_t)a.meta[(size_t)(i / nslab) * META_INTS + CSC_TILE_COLS + i % nslab];
+        __syncthreads();
+        for (int e = tid; e < NT * ntile; e += WG) {
+            const uint32_t* mk = lmask + (e / NT) * nslab;
+            const int blk = e % NT;
+            int lo = nslab, hi = 0;
+            for (int q = 0; q < nslab; ++q)
+                if ((mk[q] >> blk) & 1u) { lo = min(lo, q); hi = q + 1; }
+            brange[e] = (unsigned short)(min(lo, hi) | (hi << 8));
+        }
     }
     __syncthreads();
     const double rnorm2 = red[0] + red[1] + red[2] + red[3];
@@ -4045,13 +4054,20 @@ __global__ __launch_bounds__(WG, 2) void mmp_level_tiled16_kernel(const LevelArg
     f32x4 acc[MT][NG], accr;
     int permv[NG], permr;
     // slab range of every (bank tile, column group): outside it the group's blocks are zero padding
-    for (int e = tid; e < NG * ntile; e += WG) {
-        const int32_t* mk = a.meta + (size_t)(e / NG) * META_INTS + CSC_TILE_COLS;
-        const int g = e % NG;
-        int lo = nslab, hi = 0;
-        for (int q = 0; q < nslab; ++q)
-            if (((uint32_t)mk[q] >> (NG * g)) & 7u) { lo = min(lo, q); hi = q + 1; }
-        tl->urange[e] = (unsigned short)(min(lo, hi) | (hi << 8));
+    {
+        // (the tiles' slab masks first, all loads at once, into the idle ring: see screen16_kernel)
+        uint32_t* lmask = reinterpret_cast<uint32_t*>(ring);
+        for (int i = tid; i < ntile * nslab; i += WG)
+            lmask[i] = (uint32_t)a.meta[(size_t)(i / nslab) * META_INTS + CSC_TILE_COLS + i % nslab];
+        __syncthreads();
+        for (int e = tid; e < NG * ntile; e += WG) {
+            const uint32_t* mk = lmask + (e / NG) * nslab;
+            const int g = e % NG;
+            int lo = nslab, hi = 0;
+            for (int q = 0; q < nslab; ++q)
+                if ((mk[q] >> (NG * g)) & 7u) { lo = min(lo, q); hi = q + 1; }
+            tl->urange[e] = (unsigned short)(min(lo, hi) | (hi << 8));
+        }
     }
     __syncthreads();
     // One unit: product + masks + suppression -> the unscaled lane maximum; the entries stay in acc / accr.
